@@ -1,0 +1,236 @@
+/*
+ * rtpe_hip.h - C ABI of librtpe_hip.so: the MI355X (gfx950) inference path for
+ * the HigherHRNet-w48 teacher forward pass and the heatmap->keypoint decode.
+ *
+ * The reference (andres-fr/realtime-pose-estimation) is pure Python and has no
+ * FFI boundary of its own; the Python objects that sit on this ABI keep the
+ * reference's import paths and signatures.  Each entry
+ * point below names the reference code it replaces (paths relative to the
+ * reference repo root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device
+ *     addresses (e.g. torch.Tensor.data_ptr()), `stream` is a hipStream_t.
+ *   - every function returns 0 on success or a negative RTPE_E_* code; nothing
+ *     throws across the boundary; rtpe_last_error_string() describes the last
+ *     failure of the calling thread.
+ *   - the caller owns all inputs, outputs and workspaces.  The library owns
+ *     only what rtpe_hrnet_create() allocates (packed weights) and frees it in
+ *     rtpe_hrnet_destroy().  No device allocation, no host sync inside
+ *     rtpe_hrnet_forward() or any launch function unless documented
+ *     ("host-returning").
+ *   - all device work is enqueued on the given stream (stream-ordered,
+ *     graph-capturable); handles are independent (one process per GPU).
+ *   - activations at the boundary are NCHW (what the reference's callers pass
+ *     and expect); inside they are NHWC fp16.
+ */
+#ifndef RTPE_HIP_H
+#define RTPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTPE_OK 0
+#define RTPE_E_INVALID (-1)   /* bad argument / unsupported shape            */
+#define RTPE_E_HIP (-2)       /* a HIP runtime call failed                    */
+#define RTPE_E_NOMEM (-3)     /* workspace too small / allocation failed      */
+#define RTPE_E_NODEVICE (-4)  /* no usable gfx950 device                      */
+
+#define RTPE_DTYPE_F16 1
+#define RTPE_DTYPE_F32 2
+
+const char* rtpe_last_error_string(void);
+int rtpe_version(void);
+/* number of visible HIP devices (0 on a CPU-only host); never fails */
+int rtpe_device_count(void);
+
+/* ------------------------------------------------------------------------ *
+ * Network program.  The Python module tree (same attribute names, hence the
+ * same 1810 state-dict keys as rtpe/third_party/pose_higher_hrnet.py:259-444)
+ * compiles itself into a flat list of ops over NHWC tensors; the executor
+ * below runs it with hand-written kernels.
+ * ------------------------------------------------------------------------ */
+
+/* op kinds */
+#define RTPE_OP_STEM 0   /* 3x3 s2 conv Cin=3 + BN + ReLU from the NCHW input;
+                            pose_higher_hrnet.py:363-365,638-640 + tofp16
+                            (fp16_utils/fp16util.py:50-51)                    */
+#define RTPE_OP_CONV 1   /* kxk (1|3) stride (1|2) conv + BN/bias [+residual]
+                            [+ReLU]; BasicBlock :46-75, Bottleneck :78-116,
+                            transitions :548-583, fuse convs :200-230,
+                            final_layers :460-482                            */
+#define RTPE_OP_DECONV 2 /* ConvTranspose2d k4 s2 p1 + BN + ReLU on the channel
+                            concat of two sources; :513-524, :680-682        */
+#define RTPE_OP_FUSE 3   /* sum of up to 4 terms with nearest upsampling and a
+                            final ReLU; HighResolutionModule.forward :245-254 */
+
+/* op flags */
+#define RTPE_F_RELU 1
+#define RTPE_F_ROUND_CONV 2 /* round the fp32 accumulator to fp16 before the
+                               affine (conv and BN are separate fp16 ops in the
+                               reference's half wrapper)                      */
+#define RTPE_F_OUT_PREDS 4   /* also write NCHW output 0 (preds)             */
+#define RTPE_F_OUT_REFINED 8 /* also write NCHW output 1 (refined)           */
+#define RTPE_F_NO_NHWC 16    /* skip the NHWC store (head whose only consumer
+                               is the NCHW output)                            */
+
+typedef struct rtpe_tensor_desc {
+  int32_t channels; /* allocated channels per pixel (the NHWC row length)     */
+  int32_t ds_log2;  /* spatial size = (H >> ds_log2, W >> ds_log2)            */
+  int32_t slot;     /* workspace slot (tensors with disjoint lifetimes share) */
+  int32_t reserved;
+} rtpe_tensor_desc;
+
+typedef struct rtpe_op_desc {
+  int32_t kind;
+  int32_t flags;
+  int32_t in_t, in_coff;   /* input tensor id and first channel               */
+  int32_t out_t, out_coff; /* output tensor id and first channel              */
+  int32_t res_t, res_coff; /* residual tensor (or -1)                         */
+  int32_t cin, cout;       /* logical channel counts                          */
+  int32_t ksize, stride;
+  int64_t w_off;           /* byte offset in the raw weight blob: fp16 weights
+                              in PyTorch order (OIHW; IOHW for DECONV)         */
+  int64_t ab_off;          /* byte offset of fp32 alpha[cout] then beta[cout] */
+  int32_t n_terms;         /* FUSE: number of terms                           */
+  int32_t term_t[4];       /* FUSE: term tensor ids                           */
+  int32_t term_up[4];      /* FUSE: log2 nearest-upsampling factor per term   */
+  int32_t reserved[3];
+} rtpe_op_desc;
+
+typedef struct rtpe_hrnet rtpe_hrnet;
+
+/* Build an executor for a program.  `weights` is a HOST pointer to the raw
+ * blob (see rtpe_op_desc.w_off/ab_off); it is re-packed into MFMA fragment
+ * order and uploaded to `device`.  Replaces model construction + strict
+ * state-dict load of rtpe/helpers.py:32-73.  Host-returning. */
+int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
+                      const rtpe_tensor_desc* tensors, int32_t n_tensors,
+                      const void* weights, size_t weights_bytes,
+                      int32_t device, rtpe_hrnet** out);
+int rtpe_hrnet_destroy(rtpe_hrnet* h);
+
+/* workspace bytes for a batch of N images of H x W (multiples of 32) */
+int rtpe_hrnet_workspace_bytes(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W,
+                               size_t* bytes);
+
+/* PoseHigherResolutionNet.forward (pose_higher_hrnet.py:637-686) under the half
+ * wrapper (fp16util.py:87-91).  x: device NCHW (N,3,H,W) of x_dtype.  preds:
+ * device NCHW (N,n_preds,H/4,W/4), refined: (N,n_refined,H/2,W/2), both of
+ * out_dtype (F32 = the tofp32 cast of fp16util.py:64-68 folded in). */
+int rtpe_hrnet_forward(rtpe_hrnet* h, const void* x, int32_t x_dtype,
+                       int32_t N, int32_t H, int32_t W,
+                       void* preds, void* refined, int32_t out_dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same, but brackets every op with HIP events on `stream` and returns the
+ * per-op time in ms (op_ms[n_ops]).  Host-returning (synchronises). */
+int rtpe_hrnet_forward_timed(rtpe_hrnet* h, const void* x, int32_t x_dtype,
+                             int32_t N, int32_t H, int32_t W,
+                             void* preds, void* refined, int32_t out_dtype,
+                             void* workspace, size_t workspace_bytes, void* stream,
+                             float* op_ms, int32_t n_ops);
+
+/* algorithmic cost of op i for (N,H,W): flops and HBM bytes of a layer-fused
+ * execution (SURVEY.md section 8d accounting). */
+int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W,
+                       double* flops, double* bytes);
+
+/* ------------------------------------------------------------------------ *
+ * Single layers (layer-level parity tests; same kernels the executor runs).
+ * ------------------------------------------------------------------------ */
+
+/* NHWC fp16 conv: y = act( round16( round16?(conv(x,w)) * alpha + beta ) [+ res] ).
+ * w: HOST pointer, fp16 OIHW (cout,cin,k,k); alpha/beta: HOST fp32[cout].
+ * x:(N,H,W,cin) y:(N,Ho,Wo,cout) res:(N,Ho,Wo,cout) or NULL, device, dense.
+ * Host-returning (packs + uploads the weights, then syncs). */
+int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
+                     const void* w_host, const float* alpha_host, const float* beta_host,
+                     int32_t cout, int32_t ksize, int32_t stride, int32_t flags,
+                     const void* res, void* y, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Decode: validate_hhrnet.py:94-98 + rtpe/third_party/group.py:125-287.
+ * ------------------------------------------------------------------------ */
+
+/* F.interpolate(mode="bilinear", align_corners=True), fp32 NCHW planes.
+ * validate_hhrnet.py:94-98.  src (planes,h,w) -> dst (planes,oh,ow). */
+int rtpe_bilinear_upsample(const float* src, int32_t planes, int32_t h, int32_t w,
+                           float* dst, int32_t oh, int32_t ow, void* stream);
+
+/* HeatmapParser.nms, group.py:134-138: det * (maxpool_kxk(det) == det). */
+int rtpe_nms(const float* det, int32_t planes, int32_t h, int32_t w,
+             int32_t ksize, int32_t pad, float* out, void* stream);
+
+/* HeatmapParser.top_k, group.py:144-179, on already-upsampled maps.
+ * det (planes,h,w) f32 with planes = N*J; tag (planes_tag,h,w,D) f32 where
+ * planes_tag = planes (tag_per_joint) or N (then `joints` maps are shared);
+ * K = max_num_people.  Outputs (device): val_k (planes,K) f32, ind_k (planes,K)
+ * i32 flat index, tag_k (planes,K,D) f32.  Ties in value are ordered by
+ * ascending index.  scratch: device, rtpe_topk_scratch_bytes(). */
+int rtpe_topk(const float* det, const float* tag, int32_t planes, int32_t joints,
+              int32_t tag_per_joint, int32_t h, int32_t w, int32_t D, int32_t K,
+              int32_t nms_ksize, int32_t nms_pad,
+              float* val_k, int32_t* ind_k, float* tag_k,
+              void* scratch, size_t scratch_bytes, void* stream);
+int rtpe_topk_scratch_bytes(int32_t planes, int32_t h, int32_t w, int32_t K, size_t* bytes);
+
+/* Fused variant: bilinear upsample of the low-res network outputs + NMS +
+ * top-k + tag gather, never materialising the (oh,ow) maps (D = 1).
+ * Plane p = n*J + j of the heat maps lives at hm + n*hm_img_stride + j*hh*hw
+ * (elements), the tag plane at tg + n*tg_img_stride + j*th*tw, so the forward
+ * outputs can be passed as they are (refined; preds + 17*th*tw with an image
+ * stride of 34*th*tw). */
+int rtpe_topk_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
+                    const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride,
+                    int32_t N, int32_t J, int32_t oh, int32_t ow, int32_t K,
+                    int32_t nms_ksize, int32_t nms_pad,
+                    float* val_k, int32_t* ind_k, float* tag_k,
+                    void* scratch, size_t scratch_bytes, void* stream);
+
+/* match_by_tag, group.py:26-97 (+ py_max_match :19-23, Params :100-110) for
+ * one image.  HOST function, no GPU needed.  tag_k (J,K,D) f32, ind_k (J,K)
+ * i32 flat indices (x = ind % w, y = ind / w), val_k (J,K) f32.  Writes up to
+ * max_people_out persons as rows (J, 3+D) f32 (x, y, val, tag...) into `ans`
+ * and returns the TOTAL number of persons found in *n_people (may exceed
+ * max_people_out; then only the first max_people_out are written). */
+int rtpe_match_by_tag(const float* tag_k, const int32_t* ind_k, const float* val_k,
+                      int32_t J, int32_t K, int32_t D, int32_t w,
+                      int32_t max_num_people, double detection_threshold,
+                      double tag_threshold, int32_t use_detection_val,
+                      int32_t ignore_too_much,
+                      float* ans, int32_t max_people_out, int32_t* n_people);
+
+/* py_max_match, group.py:19-23 (Munkres().compute of the PyPI package
+ * `munkres`).  HOST function.  cost: nr x nc row-major; pairs: 2*min(nr,nc)
+ * ints out as (row, col); *n_pairs = pairs written. */
+int rtpe_munkres(const double* cost, int32_t nr, int32_t nc, int32_t* pairs, int32_t* n_pairs);
+
+/* HeatmapParser.adjust (group.py:181-200) + .refine (group.py:202-264) on
+ * the GPU for P persons (of possibly several images).  det (planes,h,w) f32,
+ * tag (planes,h,w,D) f32 device maps with planes = N*J; ans_in (P,J,3+D) f32
+ * device is read, ans_out (same shape, a different buffer) is written: every
+ * detected joint is adjusted (if do_adjust), every undetected one is searched
+ * for by the tag-penalised arg-max (if do_refine), the rest is copied.  person_img (P) i32 device = image index of each person (NULL:
+ * all image 0).  scores (P) f32 device = mean val per person before refine
+ * (group.py:272); may be NULL. */
+int rtpe_adjust_refine(const float* det, const float* tag, int32_t J, int32_t h, int32_t w,
+                       int32_t D, const float* ans_in, float* ans_out, const int32_t* person_img,
+                       int32_t P, int32_t do_adjust, int32_t do_refine, float* scores, void* stream);
+
+/* Fused variant working from the low-res maps (bilinear evaluated on the fly,
+ * D = 1; addressing as in rtpe_topk_fused). */
+int rtpe_adjust_refine_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
+                             const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride,
+                             int32_t J, int32_t oh, int32_t ow,
+                             const float* ans_in, float* ans_out, const int32_t* person_img, int32_t P,
+                             int32_t do_adjust, int32_t do_refine, float* scores, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTPE_HIP_H */

@@ -1,0 +1,368 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC fp16 in/out, fp32
+// accumulate on v_mfma_f32_16x16x32_f16, fused BN/bias + residual + ReLU
+// epilogue with the rounding points of the reference's half wrapper.
+//
+// Replaces the stock nn.Conv2d + nn.BatchNorm2d (+ add, + ReLU) launches of
+// rtpe/third_party/pose_higher_hrnet.py (BasicBlock :59-75, Bottleneck :96-116,
+// transitions :548-583, fuse convs :200-230, final_layers :460-482, and the four
+// parity classes of the k4s2 ConvTranspose2d :513-524).
+//
+// Mapping (MI355X-first, not a GEMM library call):
+//   * one workgroup = WAVES waves = a TH x TW tile of output positions of one
+//     image x one block of 16*MT output channels;
+//   * the (TH*s+k-1) x (TW*s+k-1) input halo tile of CC channels is staged ONCE
+//     into LDS (NHWC, 16-B slots, pixel stride == 32 mod 64 bytes so that the
+//     ds_read_b128 lane groups hit distinct bank slots) and re-read by all k*k
+//     taps: no im2col buffer ever exists in HBM;
+//   * MFMA orientation D[cout][pixel] = W[cout][k] * X[k][pixel]: weights are
+//     the A operand, pre-packed on the host in exact fragment order (one 1-KiB
+//     coalesced global_load_dwordx4 per fragment, L2-resident), pixels are the
+//     B operand (one ds_read_b128 per lane: 8 consecutive channels of one tap);
+//     the accumulator then holds 4 consecutive channels of one pixel per lane,
+//     i.e. the NHWC store / residual load are 8-byte row pieces;
+//   * K order inside a channel chunk is flat [tap][channel], padded to 32, so
+//     Cin = 48 needs 14 MFMA k-steps for 9 taps instead of 18.
+#include "rtpe_common.h"
+
+namespace rtpe {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kTapTableBytes = 512;
+
+__device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }
+
+template <int MT, int NT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* tapoff = reinterpret_cast<int*>(smem);
+  char* tile = smem + kTapTableBytes;
+
+  constexpr int NTHREADS = WAVES * 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int r = lane & 15;
+  const int g = lane >> 4;
+
+  // block -> (image, tile row, tile col), cout block
+  uint32_t t = blockIdx.x;
+  const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
+  const uint32_t n = fdiv(t, a.div_tiles_xy);
+  t -= n * tiles_xy;
+  const uint32_t tyi = fdiv(t, a.div_tiles_x);
+  const uint32_t txi = t - tyi * a.tiles_x;
+  const int cb = blockIdx.y;
+  const int py0 = tyi * a.th, px0 = txi * a.tw;
+  const int iy0 = py0 * a.in_mul + a.lo_y, ix0 = px0 * a.in_mul + a.lo_x;
+
+  // LDS byte offset of (tap, channel) for every (k chunk, lane group)
+  const int kvalid = a.ntaps * a.cc;
+  for (int i = tid; i < a.kc * 4; i += NTHREADS) {
+    int kk = (i >> 2) * 32 + (i & 3) * 8;
+    if (kk >= kvalid) kk -= kvalid;  // zero-weight padding: any finite in-tile data will do
+    const int tap = fdiv(kk, a.div_cc);
+    const int c = kk - tap * a.cc;
+    const int tyy = (a.tapw == 3) ? (tap * 11 >> 5) : (a.tapw == 2 ? (tap >> 1) : 0);
+    const int txx = tap - tyy * a.tapw;
+    tapoff[i] = (tyy * a.halo_w + txx) * a.pstride + c * 2;
+  }
+
+  // per-lane pixel of each N tile
+  int pixbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const uint32_t p = (wv * NT + nt) * 16 + r;
+    const uint32_t oy = fdiv(p, a.div_tw);
+    const uint32_t ox = p - oy * a.tw;
+    pixbase[nt] = (int)((oy * a.in_mul * a.halo_w + ox * a.in_mul) * a.pstride);
+  }
+
+  float4v acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  const int n_k = a.n_cchunks * a.kc;  // total k chunks
+  const half8* wfrag = reinterpret_cast<const half8*>(a.w) + (size_t)cb * n_k * MT * 64 + lane;
+
+  half8 a_cur[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_cur[m] = wfrag[m * 64];
+
+  const int slots = a.cc >> 3;               // 16-B slots per staged pixel
+  const int rowslots = a.halo_w * slots;     // per halo row
+  const int total = a.halo_h * rowslots;
+  const _Float16* xin = a.x + (size_t)n * a.H_in * a.W_in * a.in_ld;
+
+  int kf = 0;  // linear k-chunk index over (channel chunk, k chunk)
+  for (int cci = 0; cci < a.n_cchunks; ++cci) {
+    if (cci > 0) __syncthreads();
+    // ---- stage the halo tile of channels [cci*cc, cci*cc+cc) ----
+    const int cbase = cci * a.cc;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += NTHREADS) {
+      const uint32_t hy = fdiv(idx, a.div_rowslots);
+      const uint32_t q = idx - hy * rowslots;
+      const uint32_t hx = fdiv(q, a.div_slots);
+      const uint32_t s = q - hx * slots;
+      const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in &&
+          cbase + (int)s * 8 < a.cin)
+        v = *reinterpret_cast<const uint4*>(xin + ((size_t)iy * a.W_in + ix) * a.in_ld + cbase + s * 8);
+      *reinterpret_cast<uint4*>(tile + (hy * a.halo_w + hx) * a.pstride + s * 16) = v;
+    }
+    __syncthreads();
+
+    // ---- k loop over [tap][channel] of this chunk ----
+    for (int kci = 0; kci < a.kc; ++kci, ++kf) {
+      half8 a_nxt[MT];
+      const int kn = (kf + 1 < n_k) ? kf + 1 : kf;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_nxt[m] = wfrag[(size_t)(kn * MT + m) * 64];
+      const int off = tapoff[kci * 4 + g];
+      half8 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        b[nt] = *reinterpret_cast<const half8*>(tile + pixbase[nt] + off);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[m], b[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    }
+  }
+
+  // ---- epilogue: lane holds channels cbase4..cbase4+3 of pixel (nt, r) ----
+  float4v al[MT], be[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int c4 = (cb * MT + m) * 16 + g * 4;
+    al[m] = *reinterpret_cast<const float4v*>(a.alpha + c4);
+    be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const uint32_t p = (wv * NT + nt) * 16 + r;
+    const uint32_t oyt = fdiv(p, a.div_tw);
+    const uint32_t oxt = p - oyt * a.tw;
+    const int py = py0 + (int)oyt, px = px0 + (int)oxt;
+    if (py >= a.H_pos || px >= a.W_pos) continue;
+    const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+    const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int c4 = (cb * MT + m) * 16 + g * 4;
+      float4v v = acc[m][nt];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = v[j];
+        if (a.round_conv) x = round16(x);
+        x = round16(__builtin_fmaf(x, al[m][j], be[m][j]));
+        v[j] = x;
+      }
+      if (a.res != nullptr && c4 < a.cout_store) {
+        const half4 rr = *reinterpret_cast<const half4*>(a.res + pix * a.res_ld + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = round16(v[j] + (float)rr[j]);
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+      }
+      if (a.y != nullptr && c4 < a.cout_store) {
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+        *reinterpret_cast<half4*>(a.y + pix * a.out_ld + c4) = o;
+      }
+      if (a.y_nchw != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = c4 + j;
+          if (c < a.nchw_channels) {
+            const size_t o = (((size_t)n * a.nchw_channels + c) * a.H_full + oy) * a.W_full + ox;
+            if (a.nchw_f32)
+              reinterpret_cast<float*>(a.y_nchw)[o] = v[j];
+            else
+              reinterpret_cast<_Float16*>(a.y_nchw)[o] = (_Float16)v[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+ConvPlan conv_make_plan(const ConvGeom& g) {
+  ConvPlan p;
+  memset(&p, 0, sizeof(p));
+  const bool dc = g.deconv_class >= 0;
+  p.tapw = dc ? 2 : g.ksize;
+  p.in_mul = dc ? 1 : g.stride;
+  if (dc) {
+    p.lo_y = (g.deconv_class >> 1) == 0 ? -1 : 0;
+    p.lo_x = (g.deconv_class & 1) == 0 ? -1 : 0;
+  } else {
+    p.lo_y = p.lo_x = -(g.ksize / 2);
+  }
+  p.mt = (g.cout % 48 == 0 || g.cout < 48) ? 3 : 4;
+  if (g.cout <= 32) p.mt = (g.cout + 15) / 16;
+  p.cout_pad = round_up(g.cout, 16 * p.mt);
+  p.n_cb = p.cout_pad / (16 * p.mt);
+  const int cin8 = round_up(g.cin, 8);
+  if (p.tapw == 1) {
+    // 1x1: largest chunk <= 128 that divides cin and is a multiple of 32
+    p.cc = 0;
+    for (int c = 128; c >= 32; c -= 32)
+      if (cin8 % c == 0) { p.cc = c; break; }
+    if (!p.cc) p.cc = round_up(cin8 < 128 ? cin8 : 64, 16);
+  } else {
+    if (cin8 % 48 == 0) p.cc = 48;
+    else if (cin8 % 64 == 0) p.cc = 64;
+    else if (cin8 % 32 == 0) p.cc = 32;
+    else p.cc = round_up(cin8 < 64 ? cin8 : 48, 16);
+  }
+  p.n_cchunks = (cin8 + p.cc - 1) / p.cc;
+  p.kc = (p.tapw * p.tapw * p.cc + 31) / 32;
+  p.pstride = p.cc * 2;
+  while (p.pstride % 64 != 32) p.pstride += 16;
+  p.packed_bytes = (size_t)p.n_cb * p.n_cchunks * p.kc * p.mt * 64 * 8 * sizeof(uint16_t);
+  return p;
+}
+
+void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const uint16_t* w, uint16_t* packed) {
+  const int ntaps = p.tapw * p.tapw;
+  const bool dc = g.deconv_class >= 0;
+  const int ca = dc ? (g.deconv_class >> 1) : 0, cbb = dc ? (g.deconv_class & 1) : 0;
+  size_t o = 0;
+  for (int cb = 0; cb < p.n_cb; ++cb)
+    for (int cci = 0; cci < p.n_cchunks; ++cci)
+      for (int kci = 0; kci < p.kc; ++kci)
+        for (int m = 0; m < p.mt; ++m)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j, ++o) {
+              const int co = (cb * p.mt + m) * 16 + (lane & 15);
+              const int kk = kci * 32 + 8 * (lane >> 4) + j;
+              const int tap = kk / p.cc, c = cci * p.cc + kk % p.cc;
+              uint16_t v = 0;
+              if (tap < ntaps && co < g.cout && c < g.cin) {
+                const int ty = tap / p.tapw, tx = tap % p.tapw;
+                if (!dc) {
+                  v = w[(((size_t)co * g.cin + c) * g.ksize + ty) * g.ksize + tx];
+                } else {
+                  // oy = 2*iy - 1 + ky  =>  class a=0: dy=-1 -> ky=3, dy=0 -> ky=1
+                  //                         class a=1: dy=0  -> ky=2, dy=+1 -> ky=0
+                  const int ky = ca == 0 ? (ty == 0 ? 3 : 1) : (ty == 0 ? 2 : 0);
+                  const int kx = cbb == 0 ? (tx == 0 ? 3 : 1) : (tx == 0 ? 2 : 0);
+                  v = w[(((size_t)c * g.cout + co) * 4 + ky) * 4 + kx];  // IOHW
+                }
+              }
+              packed[o] = v;
+            }
+}
+
+struct TileCand { int waves, nt, th, tw; };
+static const TileCand kCands[] = {
+    {4, 8, 16, 32}, {4, 8, 32, 16}, {4, 4, 16, 16}, {4, 4, 8, 32}, {4, 4, 32, 8},
+    {4, 2, 8, 16},  {4, 2, 16, 8},  {5, 5, 20, 20}, {5, 5, 10, 40}, {5, 5, 40, 10},
+    {4, 5, 16, 20}, {4, 5, 20, 16}, {4, 5, 8, 40},  {4, 5, 40, 8},
+};
+
+static size_t tile_lds(const ConvPlan& p, int th, int tw) {
+  const int hh = (th - 1) * p.in_mul + p.tapw, hw = (tw - 1) * p.in_mul + p.tapw;
+  return (size_t)kTapTableBytes + (size_t)hh * hw * p.pstride;
+}
+
+ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+  static const long lds_cap = getenv("RTPE_CONV_LDS_CAP") ? atol(getenv("RTPE_CONV_LDS_CAP")) : 80 * 1024;
+  static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
+  double best_score = 1e30;
+  ConvTile best;
+  memset(&best, 0, sizeof(best));
+  for (const TileCand& c : kCands) {
+    if (p.mt == 4 && c.nt == 8) continue;  // 128 accumulators + operands: keep 2 waves/SIMD
+    if (force_nt && c.nt != force_nt && !(c.nt == 5)) continue;
+    const size_t lds = tile_lds(p, c.th, c.tw);
+    if ((long)lds > lds_cap && !(c.nt == 2)) continue;
+    const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw);
+    const double waste = (double)tiles * c.th * c.tw / ((double)H_pos * W_pos);
+    const long wgs = tiles * N * p.n_cb;
+    // cost model: padded work, penalise grids that cannot fill 256 CUs twice,
+    // reward pixel-tile reuse of each weight fragment (nt) and small halos
+    double score = waste;
+    if (wgs < 512) score *= 1.0 + 0.25 * (512.0 - wgs) / 512.0;
+    score *= 1.0 + 0.4 / c.nt;
+    const double halo = (double)((c.th - 1) * p.in_mul + p.tapw) * ((c.tw - 1) * p.in_mul + p.tapw) /
+                        ((double)c.th * c.tw * p.in_mul * p.in_mul);
+    score *= 1.0 + 0.1 * (halo - 1.0);
+    if (score < best_score) {
+      best_score = score;
+      best.nt = c.nt; best.waves = c.waves; best.th = c.th; best.tw = c.tw; best.lds_bytes = lds;
+    }
+  }
+  return best;
+}
+
+void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, ConvArgs* a) {
+  a->cin = g.cin; a->cout = g.cout;
+  a->tapw = p.tapw; a->ntaps = p.tapw * p.tapw;
+  a->lo_y = p.lo_y; a->lo_x = p.lo_x;
+  a->in_mul = p.in_mul;
+  a->cc = p.cc; a->n_cchunks = p.n_cchunks; a->kc = p.kc; a->pstride = p.pstride;
+  a->th = t.th; a->tw = t.tw;
+  a->halo_h = (t.th - 1) * p.in_mul + p.tapw;
+  a->halo_w = (t.tw - 1) * p.in_mul + p.tapw;
+  a->tiles_x = (a->W_pos + t.tw - 1) / t.tw;
+  a->tiles_y = (a->H_pos + t.th - 1) / t.th;
+  a->div_tw = make_fastdiv(t.tw);
+  a->div_slots = make_fastdiv(p.cc / 8);
+  a->div_rowslots = make_fastdiv(a->halo_w * (p.cc / 8));
+  a->div_cc = make_fastdiv(p.cc);
+  a->div_tiles_x = make_fastdiv(a->tiles_x);
+  a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
+}
+
+template <int MT, int NT, int WAVES>
+static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_mfma_kernel<MT, NT, WAVES>;
+  if (!attr_set) {
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y), (unsigned)n_cb);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), t.lds_bytes, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
+  RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves, "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
+  RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
+  RTPE_REQUIRE(a.kc * 4 * sizeof(int) <= (size_t)kTapTableBytes, "k chunk table overflow (kc=%d)", a.kc);
+  RTPE_REQUIRE(a.in_ld % 8 == 0 && (a.y == nullptr || a.out_ld % 4 == 0), "conv: in_ld %% 8 / out_ld %% 4");
+  RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
+#define RTPE_V(MTv, NTv, Wv) \
+  if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_variant<MTv, NTv, Wv>(t, a, p.n_cb, s);
+  RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5)
+  RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5)
+  RTPE_V(2, 8, 4) RTPE_V(2, 4, 4) RTPE_V(2, 2, 4) RTPE_V(2, 5, 4) RTPE_V(2, 5, 5)
+  RTPE_V(1, 8, 4) RTPE_V(1, 4, 4) RTPE_V(1, 2, 4) RTPE_V(1, 5, 4) RTPE_V(1, 5, 5)
+#undef RTPE_V
+  set_error("conv: no kernel variant mt=%d nt=%d waves=%d", p.mt, t.nt, t.waves);
+  return RTPE_E_INVALID;
+}
+
+}  // namespace rtpe

@@ -1,0 +1,548 @@
+// Heatmap -> keypoint decode on gfx950: bilinear upsample, 5x5 max-pool NMS,
+// top-K per (image, joint), tag gather, quarter-pixel adjust, tag-penalised
+// arg-max refine.  Replaces validate_hhrnet.py:94-98 and the device side of
+// rtpe/third_party/group.py:125-287 of the reference.
+//
+// Everything here is HBM/latency-bound integer + fp32 compare work, so the
+// design goal is to touch the low-resolution network outputs once and never
+// materialise the upsampled (h, w) maps (fused path): a sampler evaluates
+// PyTorch-CPU's exact bilinear formula on the fly.  Bit-exactness rules:
+//   * compiled with -ffp-contract=off; the fused multiply-adds that PyTorch's
+//     CPU kernel performs are written explicitly (T = fma(v0,l0,v1*l1)),
+//   * ties in top-K and arg-max go to the lowest flat index (np.argmax /
+//     first-occurrence semantics); keys are (order-preserving value bits << 32
+//     | ~index) so one unsigned 64-bit max does both.
+#include "rtpe_common.h"
+
+namespace rtpe {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------
+// samplers
+// ---------------------------------------------------------------------------
+struct DirectMap {          // dense (planes, h, w)
+  const float* p;
+  int h, w;
+  __device__ __forceinline__ float at(int plane, int y, int x) const {
+    return p[((size_t)plane * h + y) * w + x];
+  }
+};
+
+struct Axis {               // one axis of F.interpolate(bilinear, align_corners=True)
+  float scale;              // float(in-1)/float(out-1)
+  int n_in, same;
+  __device__ __forceinline__ void at(int o, int* i0, int* i1, float* l0, float* l1) const {
+    if (same) { *i0 = *i1 = o; *l0 = 1.f; *l1 = 0.f; return; }
+    const float real = scale * (float)o;
+    int a = (int)real;
+    a = a < n_in - 1 ? a : n_in - 1;
+    *i0 = a;
+    *i1 = a + (a < n_in - 1 ? 1 : 0);
+    float l = real - (float)a;
+    l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
+    *l1 = l;
+    *l0 = 1.f - l;
+  }
+};
+
+struct BilinearMap {        // low-res planes sampled at (oh, ow) resolution
+  const float* p;
+  int sh, sw, J;
+  long long img_stride;     // elements between images; plane j of image n at n*img_stride + j*sh*sw
+  Axis ay, ax;
+  __device__ __forceinline__ float at(int plane, int y, int x) const {
+    const int n = plane / J, j = plane - n * J;
+    const float* b = p + (size_t)n * img_stride + (size_t)j * sh * sw;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    ay.at(y, &y0, &y1, &ly0, &ly1);
+    ax.at(x, &x0, &x1, &lx0, &lx1);
+    const float v00 = b[y0 * sw + x0], v01 = b[y0 * sw + x1];
+    const float v10 = b[y1 * sw + x0], v11 = b[y1 * sw + x1];
+    const float t0 = __builtin_fmaf(v00, lx0, v01 * lx1);
+    const float t1 = __builtin_fmaf(v10, lx0, v11 * lx1);
+    return __builtin_fmaf(t0, ly0, t1 * ly1);
+  }
+};
+
+static Axis make_axis(int n_in, int n_out) {
+  Axis a;
+  a.n_in = n_in;
+  a.same = n_in == n_out;
+  a.scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+  return a;
+}
+
+__device__ __forceinline__ unsigned order_bits(float v) {   // monotone float -> uint
+  if (v == 0.f) v = 0.f;                                     // -0 == +0
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorder_bits(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float v, unsigned idx) {
+  return ((u64)order_bits(v) << 32) | (u64)(0xffffffffu - idx);
+}
+
+__device__ __forceinline__ u64 wave_max(u64 k) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)k, o), hi = __shfl_xor((unsigned)(k >> 32), o);
+    const u64 other = ((u64)hi << 32) | lo;
+    k = other > k ? other : k;
+  }
+  return k;
+}
+
+// block-wide max of a key; red must hold blockDim/64 entries; all threads get the result
+__device__ __forceinline__ u64 block_max(u64 k, u64* red) {
+  k = wave_max(k);
+  const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wv] = k;
+  __syncthreads();
+  u64 r = red[0];
+  for (int i = 1; i < nw; ++i) r = red[i] > r ? red[i] : r;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// plain bilinear upsample and NMS (API parity with F.interpolate / parser.nms)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bilinear_kernel(BilinearMap m, int planes, int oh, int ow, float* dst) {
+  const size_t total = (size_t)planes * oh * ow;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % ow);
+    const size_t r = i / ow;
+    const int y = (int)(r % oh), pl = (int)(r / oh);
+    dst[i] = m.at(pl, y, x);
+  }
+}
+
+constexpr int kTH = 32, kTW = 64;   // NMS / top-k tile (2048 px, 8 per thread)
+constexpr int kMaxPad = 4;          // supports nms kernels up to 9x9
+
+template <class Map>
+__device__ __forceinline__ void nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
+                                         float* raw, float* rowmax) {
+  // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
+  const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
+  for (int i = threadIdx.x; i < PH * PW; i += 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int y = y0 - pad + py, x = x0 - pad + px;
+    raw[i] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? m.at(plane, y, x) : -INFINITY;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PH * kTW; i += 256) {
+    const int py = i / kTW, px = i - py * kTW;
+    float v = raw[py * PW + px];
+    for (int d = 1; d <= 2 * pad; ++d) v = fmaxf(v, raw[py * PW + px + d]);
+    rowmax[i] = v;
+  }
+  __syncthreads();
+}
+
+template <class Map>
+__global__ void __launch_bounds__(256) nms_kernel(Map m, int h, int w, int pad, float* out) {
+  __shared__ float raw[(kTH + 2 * kMaxPad) * (kTW + 2 * kMaxPad)];
+  __shared__ float rowmax[(kTH + 2 * kMaxPad) * kTW];
+  const int tiles_x = (w + kTW - 1) / kTW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
+  const int y0 = ty * kTH, x0 = tx * kTW;
+  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax);
+  const int PW = kTW + 2 * pad;
+  for (int i = threadIdx.x; i < kTH * kTW; i += 256) {
+    const int ly = i / kTW, lx = i - ly * kTW;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= h || x >= w) continue;
+    float mx = rowmax[ly * kTW + lx];
+    for (int d = 1; d <= 2 * pad; ++d) mx = fmaxf(mx, rowmax[(ly + d) * kTW + lx]);
+    const float v = raw[(ly + pad) * PW + lx + pad];
+    out[((size_t)plane * h + y) * w + x] = v * (mx == v ? 1.f : 0.f);   // det * (maxm == det).float()
+  }
+}
+
+// ---------------------------------------------------------------------------
+// top-K, phase 1: per tile, the K best positive local maxima as sorted keys
+// ---------------------------------------------------------------------------
+template <class Map>
+__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad, int K, u64* cand) {
+  __shared__ float raw[(kTH + 2 * kMaxPad) * (kTW + 2 * kMaxPad)];
+  __shared__ float rowmax[(kTH + 2 * kMaxPad) * kTW];
+  __shared__ u64 red[4];
+  const int tiles_x = (w + kTW - 1) / kTW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
+  const int y0 = ty * kTH, x0 = tx * kTW;
+  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax);
+  const int PW = kTW + 2 * pad;
+  u64 mine[8];   // this thread's 8 pixels as keys (0 = not a positive local maximum)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = threadIdx.x + q * 256;
+    const int ly = i / kTW, lx = i - ly * kTW;
+    const int y = y0 + ly, x = x0 + lx;
+    u64 key = 0;
+    if (y < h && x < w) {
+      float mx = rowmax[ly * kTW + lx];
+      for (int d = 1; d <= 2 * pad; ++d) mx = fmaxf(mx, rowmax[(ly + d) * kTW + lx]);
+      const float v = raw[(ly + pad) * PW + lx + pad];
+      if (mx == v && v > 0.f) key = make_key(v, (unsigned)(y * w + x));
+    }
+    mine[q] = key;
+  }
+  u64* outp = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;
+  for (int k = 0; k < K; ++k) {
+    u64 best = mine[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) best = mine[q] > best ? mine[q] : best;
+    best = block_max(best, red);
+    if (threadIdx.x == 0) outp[k] = best;
+    if (best == 0) {              // exhausted: the rest of the list is empty
+      for (int r = k + 1 + threadIdx.x; r < K; r += 256) outp[r] = 0;
+      break;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (mine[q] == best) mine[q] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// top-K, phase 2: merge the per-tile lists of one plane, gather tags, pad with
+// zero-valued pixels in index order (what a stable top-k of the NMS map gives)
+// ---------------------------------------------------------------------------
+template <class Map>
+__device__ float nms_value_at(const Map& m, int plane, int h, int w, int pad, int y, int x) {
+  const float v = m.at(plane, y, x);
+  float mx = v;
+  for (int dy = -pad; dy <= pad; ++dy)
+    for (int dx = -pad; dx <= pad; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) mx = fmaxf(mx, m.at(plane, yy, xx));
+    }
+  return v * (mx == v ? 1.f : 0.f);
+}
+
+template <class Map, class TagMap>
+__global__ void __launch_bounds__(256) topk_merge_kernel(Map m, TagMap tm, int tag_shared_joints, int D,
+                                                         int h, int w, int pad, int K, int tiles,
+                                                         u64* cand, float* val_k, int* ind_k, float* tag_k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  u64* red = reinterpret_cast<u64*>(smem_raw);          // 4 entries
+  u64* lkeys = red + 4;
+  const int plane = blockIdx.x;
+  const int n = tiles * K;
+  u64* gk = cand + (size_t)plane * n;
+  const bool use_lds = (size_t)n * 8 + 32 <= 150 * 1024;
+  u64* keys = gk;                                         // flat pointer: LDS copy when it fits
+  if (use_lds) {
+    for (int i = threadIdx.x; i < n; i += 256) lkeys[i] = gk[i];
+    __syncthreads();
+    keys = lkeys;
+  }
+  const int tag_plane = tag_shared_joints > 0 ? plane / tag_shared_joints : plane;
+  int found = 0;
+  for (int k = 0; k < K; ++k) {
+    u64 best = 0;
+    for (int i = threadIdx.x; i < n; i += 256) best = keys[i] > best ? keys[i] : best;
+    best = block_max(best, red);
+    if (best == 0) break;
+    for (int i = threadIdx.x; i < n; i += 256)
+      if (keys[i] == best) keys[i] = 0;
+    if (threadIdx.x == 0) {
+      const unsigned idx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
+      val_k[(size_t)plane * K + k] = unorder_bits((unsigned)(best >> 32));
+      ind_k[(size_t)plane * K + k] = (int)idx;
+    }
+    ++found;
+    __syncthreads();
+  }
+  // zero padding (single thread; K - found is almost always tiny work)
+  if (threadIdx.x == 0 && found < K) {
+    int k = found;
+    for (int idx = 0; idx < h * w && k < K; ++idx) {
+      const float v = nms_value_at(m, plane, h, w, pad, idx / w, idx - (idx / w) * w);
+      if (v == 0.f) {
+        val_k[(size_t)plane * K + k] = 0.f;
+        ind_k[(size_t)plane * K + k] = idx;
+        ++k;
+      }
+    }
+    for (; k < K; ++k) { val_k[(size_t)plane * K + k] = 0.f; ind_k[(size_t)plane * K + k] = 0; }
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int i = threadIdx.x; i < K * D; i += 256) {
+    const int k = i / D, d = i - k * D;
+    const int idx = ind_k[(size_t)plane * K + k];
+    tag_k[((size_t)plane * K + k) * D + d] = tm.at(tag_plane, idx / w, idx - (idx / w) * w, d);
+  }
+}
+
+struct DirectTag {          // (planes, h, w, D)
+  const float* p;
+  int h, w, D;
+  __device__ __forceinline__ float at(int plane, int y, int x, int d) const {
+    return p[(((size_t)plane * h + y) * w + x) * D + d];
+  }
+};
+struct BilinearTag {        // D == 1
+  BilinearMap m;
+  __device__ __forceinline__ float at(int plane, int y, int x, int) const { return m.at(plane, y, x); }
+};
+
+// ---------------------------------------------------------------------------
+// adjust + refine: one workgroup per (person, joint)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float pairwise8_sum(const float* a, int n) {   // numpy contiguous f32 add.reduce
+  if (n < 8) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s = s + a[i];
+    return s;
+  }
+  float r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i + 8 <= n; i += 8)
+    for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+  float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) s = s + a[i];
+  return s;
+}
+
+constexpr int kMaxJ = 32, kMaxD = 32;
+
+template <class Map, class TagMap>
+__global__ void __launch_bounds__(256) adjust_refine_kernel(Map m, TagMap tm, int J, int h, int w, int D,
+                                                            const float* ans_in, float* ans_out,
+                                                            const int* person_img, int do_adjust,
+                                                            int do_refine, float* scores) {
+  // Block (p, j) reads the person's rows only from ans_in (the state before any
+  // fill, as group.py:214-222 collects the tags first) and owns row (p, j) of
+  // ans_out.
+  __shared__ u64 red[4];
+  __shared__ float mean_tag[kMaxD];
+  const int p = blockIdx.x / J, j = blockIdx.x - p * J;
+  const int img = person_img ? person_img[p] : 0;
+  const int plane = img * J + j;
+  const int row_len = 3 + D;
+  const float* kp = ans_in + (size_t)p * J * row_len;
+  float* out = ans_out + ((size_t)p * J + j) * row_len;
+  const float val = kp[j * row_len + 2];
+  if (threadIdx.x < row_len) out[threadIdx.x] = kp[j * row_len + threadIdx.x];
+  __syncthreads();
+
+  if (threadIdx.x == 0 && j == 0 && scores) {           // group.py:272 (before refine)
+    float v[kMaxJ];
+    for (int q = 0; q < J; ++q) v[q] = kp[q * row_len + 2];
+    scores[p] = pairwise8_sum(v, J) / (float)J;
+  }
+  if (val > 0.f) {                                        // adjust, group.py:181-200
+    if (do_adjust && threadIdx.x == 0) {
+      float cx = kp[j * row_len + 0], cy = kp[j * row_len + 1];
+      const int col = (int)cx, row = (int)cy;
+      const int cr = col + 1 < w - 1 ? col + 1 : w - 1, cl = col - 1 > 0 ? col - 1 : 0;
+      const int rd = row + 1 < h - 1 ? row + 1 : h - 1, ru = row - 1 > 0 ? row - 1 : 0;
+      cx += m.at(plane, row, cr) > m.at(plane, row, cl) ? 0.25f : -0.25f;
+      cy += m.at(plane, rd, col) > m.at(plane, ru, col) ? 0.25f : -0.25f;
+      out[0] = cx + 0.5f;
+      out[1] = cy + 0.5f;
+    }
+    return;
+  }
+  if (!do_refine || val != 0.f) return;                   // refine fills joints with val == 0 only
+
+  // mean tag of the detected joints (the tags stored in ans are tag[j, y, x]), group.py:214-222
+  if (threadIdx.x < D) {
+    const int d = threadIdx.x;
+    float t[kMaxJ];
+    int n = 0;
+    for (int q = 0; q < J; ++q)
+      if (kp[q * row_len + 2] > 0.f) t[n++] = kp[q * row_len + 3 + d];
+    float s;
+    if (D == 1) {
+      s = pairwise8_sum(t, n);
+    } else {
+      s = 0.f;
+      for (int i = 0; i < n; ++i) s = s + t[i];
+    }
+    mean_tag[d] = s / (float)n;
+  }
+  __syncthreads();
+
+  // arg-max over the whole map of det - round(||tag - mean||), group.py:225-233
+  u64 best = 0;
+  const int total = h * w;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int y = i / w, x = i - y * w;
+    float ss;
+    if (D < 8) {
+      float d0 = tm.at(plane, y, x, 0) - mean_tag[0];
+      ss = d0 * d0;
+      for (int d = 1; d < D; ++d) {
+        const float dd = tm.at(plane, y, x, d) - mean_tag[d];
+        ss = ss + dd * dd;
+      }
+    } else {
+      float sq[kMaxD];
+      for (int d = 0; d < D; ++d) {
+        const float dd = tm.at(plane, y, x, d) - mean_tag[d];
+        sq[d] = dd * dd;
+      }
+      ss = pairwise8_sum(sq, D);
+    }
+    const float score = m.at(plane, y, x) - rintf(sqrtf(ss));
+    const u64 key = make_key(score, (unsigned)i);
+    best = key > best ? key : best;
+  }
+  best = block_max(best, red);
+  if (threadIdx.x == 0) {
+    const int idx = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+    const int y = idx / w, x = idx - y * w;
+    const float v = m.at(plane, y, x);
+    if (v > 0.f) {                                        // group.py:256-262
+      const int xr = x + 1 < w - 1 ? x + 1 : w - 1, xl = x - 1 > 0 ? x - 1 : 0;
+      const int yd = y + 1 < h - 1 ? y + 1 : h - 1, yu = y - 1 > 0 ? y - 1 : 0;
+      const float fx = (float)x + 0.5f + (m.at(plane, y, xr) > m.at(plane, y, xl) ? 0.25f : -0.25f);
+      const float fy = (float)y + 0.5f + (m.at(plane, yd, x) > m.at(plane, yu, x) ? 0.25f : -0.25f);
+      out[0] = fx;
+      out[1] = fy;
+      out[2] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host wrappers
+// ---------------------------------------------------------------------------
+static BilinearMap make_bilinear(const float* p, int sh, int sw, long long img_stride, int J, int oh, int ow) {
+  BilinearMap m;
+  m.p = p; m.sh = sh; m.sw = sw; m.J = J; m.img_stride = img_stride;
+  m.ay = make_axis(sh, oh);
+  m.ax = make_axis(sw, ow);
+  return m;
+}
+
+static size_t topk_scratch(int planes, int h, int w, int K) {
+  const size_t tiles = (size_t)((h + kTH - 1) / kTH) * ((w + kTW - 1) / kTW);
+  return (size_t)planes * tiles * K * sizeof(u64);
+}
+
+template <class Map, class TagMap>
+static int topk_run(const Map& m, const TagMap& tm, int planes, int tag_shared_joints, int D, int h, int w,
+                    int K, int ksize, int pad, float* val_k, int* ind_k, float* tag_k, void* scratch,
+                    size_t scratch_bytes, hipStream_t s) {
+  RTPE_REQUIRE(ksize == 2 * pad + 1 && pad >= 0 && pad <= kMaxPad, "nms: ksize=%d pad=%d unsupported", ksize, pad);
+  RTPE_REQUIRE(planes > 0 && h > 0 && w > 0 && K > 0 && (size_t)h * w < 0x7fffffffu, "topk: bad shape");
+  RTPE_REQUIRE(scratch_bytes >= topk_scratch(planes, h, w, K), "topk: scratch too small");
+  const int tiles = ((h + kTH - 1) / kTH) * ((w + kTW - 1) / kTW);
+  u64* cand = reinterpret_cast<u64*>(scratch);
+  hipLaunchKernelGGL((topk_tile_kernel<Map>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
+  RTPE_HIP_CHECK(hipGetLastError());
+  size_t lds = 32 + (size_t)tiles * K * 8;
+  if (lds > 150 * 1024) lds = 32;
+  auto kern = topk_merge_kernel<Map, TagMap>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(planes), dim3(256), lds, s, m, tm, tag_shared_joints, D, h, w, pad, K, tiles,
+                     cand, val_k, ind_k, tag_k);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+}  // namespace rtpe
+
+using namespace rtpe;
+
+extern "C" int rtpe_bilinear_upsample(const float* src, int32_t planes, int32_t h, int32_t w, float* dst,
+                                      int32_t oh, int32_t ow, void* stream) {
+  RTPE_REQUIRE(src && dst && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "bilinear: bad argument");
+  BilinearMap m = make_bilinear(src, h, w, 0, planes, oh, ow);   // one "image" of `planes` planes
+  const size_t total = (size_t)planes * oh * ow;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     m, planes, oh, ow, dst);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_nms(const float* det, int32_t planes, int32_t h, int32_t w, int32_t ksize, int32_t pad,
+                        float* out, void* stream) {
+  RTPE_REQUIRE(det && out && planes > 0 && h > 0 && w > 0, "nms: bad argument");
+  RTPE_REQUIRE(ksize == 2 * pad + 1 && pad >= 0 && pad <= kMaxPad, "nms: ksize=%d pad=%d unsupported", ksize, pad);
+  DirectMap m{det, h, w};
+  const int tiles = ((h + kTH - 1) / kTH) * ((w + kTW - 1) / kTW);
+  hipLaunchKernelGGL((nms_kernel<DirectMap>), dim3(tiles, planes), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), m, h, w, pad, out);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_topk_scratch_bytes(int32_t planes, int32_t h, int32_t w, int32_t K, size_t* bytes) {
+  RTPE_REQUIRE(bytes && planes > 0 && h > 0 && w > 0 && K > 0, "topk_scratch_bytes: bad argument");
+  *bytes = topk_scratch(planes, h, w, K);
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_topk(const float* det, const float* tag, int32_t planes, int32_t joints,
+                         int32_t tag_per_joint, int32_t h, int32_t w, int32_t D, int32_t K, int32_t nms_ksize,
+                         int32_t nms_pad, float* val_k, int32_t* ind_k, float* tag_k, void* scratch,
+                         size_t scratch_bytes, void* stream) {
+  RTPE_REQUIRE(det && tag && val_k && ind_k && tag_k && scratch && D > 0 && joints > 0, "topk: bad argument");
+  DirectMap m{det, h, w};
+  DirectTag tm{tag, h, w, D};
+  return topk_run(m, tm, planes, tag_per_joint ? 0 : joints, D, h, w, K, nms_ksize, nms_pad, val_k, ind_k, tag_k,
+                  scratch, scratch_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int rtpe_topk_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride, const float* tg,
+                               int32_t th, int32_t tw, int64_t tg_img_stride, int32_t N, int32_t J, int32_t oh,
+                               int32_t ow, int32_t K, int32_t nms_ksize, int32_t nms_pad, float* val_k,
+                               int32_t* ind_k, float* tag_k, void* scratch, size_t scratch_bytes, void* stream) {
+  RTPE_REQUIRE(hm && tg && val_k && ind_k && tag_k && scratch && N > 0 && J > 0, "topk_fused: bad argument");
+  BilinearMap m = make_bilinear(hm, hh, hw, hm_img_stride, J, oh, ow);
+  BilinearTag tm{make_bilinear(tg, th, tw, tg_img_stride, J, oh, ow)};
+  return topk_run(m, tm, N * J, 0, 1, oh, ow, K, nms_ksize, nms_pad, val_k, ind_k, tag_k, scratch, scratch_bytes,
+                  reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int rtpe_adjust_refine(const float* det, const float* tag, int32_t J, int32_t h, int32_t w, int32_t D,
+                                  const float* ans_in, float* ans_out, const int32_t* person_img, int32_t P,
+                                  int32_t do_adjust, int32_t do_refine, float* scores, void* stream) {
+  RTPE_REQUIRE(det && tag && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && J > 0 && J <= kMaxJ &&
+                   D > 0 && D <= kMaxD,
+               "adjust_refine: bad argument (J<=%d, D<=%d)", kMaxJ, kMaxD);
+  if (P <= 0) return RTPE_OK;
+  DirectMap m{det, h, w};
+  DirectTag tm{tag, h, w, D};
+  hipLaunchKernelGGL((adjust_refine_kernel<DirectMap, DirectTag>), dim3(P * J), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), m, tm, J, h, w, D, ans_in, ans_out, person_img,
+                     do_adjust, do_refine, scores);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_adjust_refine_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
+                                        const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride, int32_t J,
+                                        int32_t oh, int32_t ow, const float* ans_in, float* ans_out,
+                                        const int32_t* person_img, int32_t P, int32_t do_adjust,
+                                        int32_t do_refine, float* scores, void* stream) {
+  RTPE_REQUIRE(hm && tg && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && J > 0 && J <= kMaxJ,
+               "adjust_refine_fused: bad argument");
+  if (P <= 0) return RTPE_OK;
+  BilinearMap m = make_bilinear(hm, hh, hw, hm_img_stride, J, oh, ow);
+  BilinearTag tm{make_bilinear(tg, th, tw, tg_img_stride, J, oh, ow)};
+  hipLaunchKernelGGL((adjust_refine_kernel<BilinearMap, BilinearTag>), dim3(P * J), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), m, tm, J, oh, ow, 1, ans_in, ans_out, person_img,
+                     do_adjust, do_refine, scores);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}

@@ -1,0 +1,144 @@
+// Memory-bound pieces of the forward pass: the Cin=3 stem conv (NCHW fp32 in,
+// NHWC fp16 out, the tofp16 cast folded into the load) and the multi-resolution
+// fuse sum.  Both are HBM-bound: 16-byte vector accesses, one pass.
+#include "rtpe_common.h"
+
+namespace rtpe {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }
+
+// ---------------------------------------------------------------------------
+// HighResolutionModule.forward fuse sum, pose_higher_hrnet.py:245-254:
+//   y = t0; y = y + t1; ...; relu(y)   with one fp16 rounding per add.
+// Terms at a lower resolution are read with nearest-neighbour upsampling
+// (nn.Upsample(scale_factor=2**(j-i), mode='nearest'), :209), i.e. the
+// upsampled tensor is never written to HBM.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
+  const int c8 = a.C >> 3;
+  const size_t total = (size_t)a.N * a.H * a.W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cs = (int)(i % c8);
+    size_t pix = i / c8;
+    const int x = (int)(pix % a.W);
+    pix /= a.W;
+    const int y = (int)(pix % a.H);
+    const int n = (int)(pix / a.H);
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= a.n_terms) break;
+      const int u = a.term_up[t];
+      const int hs = a.H >> u, ws = a.W >> u;
+      const half8 v = *reinterpret_cast<const half8*>(
+          a.term[t] + (((size_t)n * hs + (y >> u)) * ws + (x >> u)) * a.term_ld[t] + cs * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = t == 0 ? (float)v[j] : round16(acc[j] + (float)v[j]);
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(acc[j] > 0.f ? acc[j] : 0.f);
+    *reinterpret_cast<half8*>(a.y + (((size_t)n * a.H + y) * a.W + x) * a.out_ld + cs * 8) = o;
+  }
+}
+
+int fuse_launch(const FuseArgs& a, hipStream_t s) {
+  RTPE_REQUIRE(a.C % 8 == 0 && a.n_terms >= 1 && a.n_terms <= 4, "fuse: C=%d terms=%d", a.C, a.n_terms);
+  const size_t total = (size_t)a.N * a.H * a.W * (a.C / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(fuse_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Stem conv1 + bn1 + relu, pose_higher_hrnet.py:363-365 / :638-640, with the
+// wrapper's input.half() (fp16util.py:50-51) applied at load time.
+// One thread = one output pixel x 64 channels; the 3 x 17 x 65 input patch of an
+// 8 x 32 output tile and the 27 x 64 weights sit in LDS.
+// ---------------------------------------------------------------------------
+constexpr int kStemTH = 8, kStemTW = 32, kStemCO = 64;
+constexpr int kStemPH = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 1;
+
+__global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
+  __shared__ float patch[3][kStemPH][kStemPW + 1];
+  __shared__ __attribute__((aligned(16))) float wl[27][kStemCO];
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const int tiles_x = (Wo + kStemTW - 1) / kStemTW, tiles_y = (Ho + kStemTH - 1) / kStemTH;
+  int t = blockIdx.x;
+  const int n = t / (tiles_x * tiles_y);
+  t -= n * tiles_x * tiles_y;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int oy0 = ty * kStemTH, ox0 = tx * kStemTW;
+  const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < 27 * kStemCO; i += 256) wl[i / kStemCO][i % kStemCO] = (float)a.w[i];
+  for (int i = tid; i < 3 * kStemPH * kStemPW; i += 256) {
+    const int c = i / (kStemPH * kStemPW);
+    const int rem = i - c * kStemPH * kStemPW;
+    const int py = rem / kStemPW, px = rem - py * kStemPW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+      const size_t o = (((size_t)n * 3 + c) * a.H + iy) * a.W + ix;
+      v = a.x_f32 ? round16(reinterpret_cast<const float*>(a.x)[o])
+                  : (float)reinterpret_cast<const _Float16*>(a.x)[o];
+    }
+    patch[c][py][px] = v;
+  }
+  __syncthreads();
+
+  const int ly = tid / kStemTW, lx = tid % kStemTW;
+  const int oy = oy0 + ly, ox = ox0 + lx;
+  float acc[kStemCO];
+#pragma unroll
+  for (int co = 0; co < kStemCO; ++co) acc[co] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float xv = patch[c][2 * ly + ky][2 * lx + kx];
+        const float4* wr = reinterpret_cast<const float4*>(wl[(ky * 3 + kx) * 3 + c]);
+#pragma unroll
+        for (int q = 0; q < kStemCO / 4; ++q) {
+          const float4 w4 = wr[q];
+          acc[4 * q + 0] = __builtin_fmaf(xv, w4.x, acc[4 * q + 0]);
+          acc[4 * q + 1] = __builtin_fmaf(xv, w4.y, acc[4 * q + 1]);
+          acc[4 * q + 2] = __builtin_fmaf(xv, w4.z, acc[4 * q + 2]);
+          acc[4 * q + 3] = __builtin_fmaf(xv, w4.w, acc[4 * q + 3]);
+        }
+      }
+  if (oy < Ho && ox < Wo) {
+    _Float16* dst = a.y + (((size_t)n * Ho + oy) * Wo + ox) * a.out_ld;
+#pragma unroll
+    for (int q = 0; q < kStemCO / 8; ++q) {
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int co = q * 8 + j;
+        float v = round16(acc[co]);                                   // conv output (fp16)
+        v = round16(__builtin_fmaf(v, a.alpha[co], a.beta[co]));      // BN output (fp16)
+        o[j] = (_Float16)(v > 0.f ? v : 0.f);
+      }
+      *reinterpret_cast<half8*>(dst + q * 8) = o;
+    }
+  }
+}
+
+int stem_launch(const StemArgs& a, hipStream_t s) {
+  RTPE_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0 && a.out_ld % 8 == 0, "stem: H=%d W=%d", a.H, a.W);
+  const int Ho = a.H / 2, Wo = a.W / 2;
+  const int tiles = ((Wo + kStemTW - 1) / kStemTW) * ((Ho + kStemTH - 1) / kStemTH);
+  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(tiles * a.N)), dim3(256), 0, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+}  // namespace rtpe

@@ -1,0 +1,374 @@
+// Program executor: runs the flat op list that the Python module tree compiles
+// itself into (rtpe/third_party/pose_higher_hrnet.py of this repo) with the
+// kernels of conv_mfma.hip / elementwise.hip.  Owns only the packed weights.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "rtpe_common.h"
+
+namespace rtpe {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  return RTPE_E_HIP;
+}
+
+struct OpState {
+  rtpe_op_desc d;
+  ConvGeom geom[4];   // 1 for CONV, 4 parity classes for DECONV
+  ConvPlan plan[4];
+  size_t w_dev_off[4];  // byte offsets in the device weight arena
+  size_t ab_dev_off;    // alpha then beta, fp32[cout_pad]
+  int n_geom;
+};
+
+}  // namespace rtpe
+
+using namespace rtpe;
+
+struct rtpe_hrnet {
+  int device;
+  std::vector<OpState> ops;
+  std::vector<rtpe_tensor_desc> tensors;
+  int n_slots;
+  char* arena;        // device: packed weights + affine params
+  size_t arena_bytes;
+  int n_preds, n_refined;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" const char* rtpe_last_error_string(void) { return g_err.c_str(); }
+extern "C" int rtpe_version(void) { return 1; }
+extern "C" int rtpe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
+                                 const rtpe_tensor_desc* tensors, int32_t n_tensors,
+                                 const void* weights, size_t weights_bytes, int32_t device,
+                                 rtpe_hrnet** out) {
+  RTPE_REQUIRE(ops && tensors && weights && out && n_ops > 0 && n_tensors > 0, "hrnet_create: null argument");
+  RTPE_HIP_CHECK(hipSetDevice(device));
+  rtpe_hrnet* h = new rtpe_hrnet();
+  h->device = device;
+  h->tensors.assign(tensors, tensors + n_tensors);
+  h->n_slots = 0;
+  for (auto& t : h->tensors) h->n_slots = t.slot + 1 > h->n_slots ? t.slot + 1 : h->n_slots;
+  h->n_preds = h->n_refined = 0;
+  h->arena = nullptr;
+  const char* wb = reinterpret_cast<const char*>(weights);
+
+  // pass 1: plans + arena layout
+  size_t off = 0;
+  h->ops.resize(n_ops);
+  for (int i = 0; i < n_ops; ++i) {
+    OpState& o = h->ops[i];
+    o.d = ops[i];
+    o.n_geom = 0;
+    const rtpe_op_desc& d = o.d;
+    auto bad_t = [&](int t) { return t < 0 || t >= n_tensors; };
+    if (d.kind != RTPE_OP_FUSE && d.kind != RTPE_OP_STEM && bad_t(d.in_t)) {
+      set_error("op %d: bad input tensor", i); delete h; return RTPE_E_INVALID;
+    }
+    if (bad_t(d.out_t) && !(d.flags & RTPE_F_NO_NHWC)) {
+      set_error("op %d: bad output tensor", i); delete h; return RTPE_E_INVALID;
+    }
+    if (d.flags & RTPE_F_OUT_PREDS) h->n_preds = d.cout;
+    if (d.flags & RTPE_F_OUT_REFINED) h->n_refined = d.cout;
+    if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
+      o.n_geom = d.kind == RTPE_OP_DECONV ? 4 : 1;
+      for (int k = 0; k < o.n_geom; ++k) {
+        o.geom[k] = ConvGeom{d.cin, d.cout, d.ksize, d.stride, d.kind == RTPE_OP_DECONV ? k : -1};
+        o.plan[k] = conv_make_plan(o.geom[k]);
+        o.w_dev_off[k] = off;
+        off = align_up(off + o.plan[k].packed_bytes, 256);
+      }
+      o.ab_dev_off = off;
+      off = align_up(off + 2 * sizeof(float) * o.plan[0].cout_pad, 256);
+      const size_t wbytes = (size_t)d.cin * d.cout * d.ksize * d.ksize * 2;
+      if (d.w_off < 0 || (size_t)d.w_off + wbytes > weights_bytes ||
+          d.ab_off < 0 || (size_t)d.ab_off + 8 * (size_t)d.cout > weights_bytes) {
+        set_error("op %d: weight offsets out of range", i); delete h; return RTPE_E_INVALID;
+      }
+    } else if (d.kind == RTPE_OP_STEM) {
+      o.w_dev_off[0] = off;
+      off = align_up(off + 27 * 64 * 2, 256);
+      o.ab_dev_off = off;
+      off = align_up(off + 2 * sizeof(float) * 64, 256);
+      if (d.cout != 64 || d.cin != 3) { set_error("stem must be 3->64"); delete h; return RTPE_E_INVALID; }
+    } else if (d.kind == RTPE_OP_FUSE) {
+      if (d.n_terms < 1 || d.n_terms > 4) { set_error("op %d: fuse terms", i); delete h; return RTPE_E_INVALID; }
+    } else {
+      set_error("op %d: unknown kind %d", i, d.kind); delete h; return RTPE_E_INVALID;
+    }
+  }
+  h->arena_bytes = off;
+
+  // pass 2: pack on the host, one upload
+  std::vector<char> host(off, 0);
+  for (int i = 0; i < n_ops; ++i) {
+    OpState& o = h->ops[i];
+    const rtpe_op_desc& d = o.d;
+    if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
+      for (int k = 0; k < o.n_geom; ++k)
+        conv_pack_weights(o.geom[k], o.plan[k], reinterpret_cast<const uint16_t*>(wb + d.w_off),
+                          reinterpret_cast<uint16_t*>(host.data() + o.w_dev_off[k]));
+      float* ab = reinterpret_cast<float*>(host.data() + o.ab_dev_off);
+      const float* src = reinterpret_cast<const float*>(wb + d.ab_off);
+      const int cp = o.plan[0].cout_pad;
+      for (int c = 0; c < d.cout; ++c) { ab[c] = src[c]; ab[cp + c] = src[d.cout + c]; }
+    } else if (d.kind == RTPE_OP_STEM) {
+      const uint16_t* w = reinterpret_cast<const uint16_t*>(wb + d.w_off);  // (64,3,3,3)
+      uint16_t* p = reinterpret_cast<uint16_t*>(host.data() + o.w_dev_off[0]);
+      for (int co = 0; co < 64; ++co)
+        for (int c = 0; c < 3; ++c)
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+              p[((ky * 3 + kx) * 3 + c) * 64 + co] = w[((co * 3 + c) * 3 + ky) * 3 + kx];
+      memcpy(host.data() + o.ab_dev_off, wb + d.ab_off, 2 * 64 * sizeof(float));
+    }
+  }
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->arena), off ? off : 256);
+  if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(arena)", __FILE__, __LINE__); }
+  e = hipMemcpy(h->arena, host.data(), off, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemcpy(arena)", __FILE__, __LINE__); }
+  *out = h;
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_hrnet_destroy(rtpe_hrnet* h) {
+  if (!h) return RTPE_OK;
+  if (h->arena) hipFree(h->arena);
+  delete h;
+  return RTPE_OK;
+}
+
+static void slot_layout(const rtpe_hrnet* h, int N, int H, int W, std::vector<size_t>* offs, size_t* total) {
+  std::vector<size_t> sz(h->n_slots, 0);
+  for (const auto& t : h->tensors) {
+    const size_t b = (size_t)N * (H >> t.ds_log2) * (W >> t.ds_log2) * t.channels * 2;
+    if (b > sz[t.slot]) sz[t.slot] = b;
+  }
+  offs->resize(h->n_slots);
+  size_t o = 0;
+  for (int s = 0; s < h->n_slots; ++s) { (*offs)[s] = o; o += align_up(sz[s], 256); }
+  *total = o;
+}
+
+extern "C" int rtpe_hrnet_workspace_bytes(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, size_t* bytes) {
+  RTPE_REQUIRE(h && bytes && N > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0,
+               "workspace_bytes: N=%d H=%d W=%d (H, W must be multiples of 32)", N, H, W);
+  std::vector<size_t> offs;
+  slot_layout(h, N, H, W, &offs, bytes);
+  return RTPE_OK;
+}
+
+static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
+               int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms) {
+  RTPE_REQUIRE(h && x && ws, "forward: null argument");
+  RTPE_REQUIRE(N > 0 && H % 32 == 0 && W % 32 == 0 && H >= 32 && W >= 32, "forward: N=%d H=%d W=%d", N, H, W);
+  RTPE_REQUIRE(x_dtype == RTPE_DTYPE_F16 || x_dtype == RTPE_DTYPE_F32, "forward: x dtype");
+  RTPE_REQUIRE(out_dtype == RTPE_DTYPE_F16 || out_dtype == RTPE_DTYPE_F32, "forward: out dtype");
+  std::vector<size_t> offs;
+  size_t need;
+  slot_layout(h, N, H, W, &offs, &need);
+  if (need > ws_bytes) { set_error("forward: workspace %zu < %zu", ws_bytes, need); return RTPE_E_NOMEM; }
+  RTPE_REQUIRE(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
+  char* base = reinterpret_cast<char*>(ws);
+  auto tptr = [&](int t, int coff) -> _Float16* {
+    return reinterpret_cast<_Float16*>(base + offs[h->tensors[t].slot]) + coff;
+  };
+  std::vector<hipEvent_t> ev;
+  const bool timed = op_ms != nullptr;
+  if (timed) {
+    RTPE_REQUIRE(n_ms >= (int)h->ops.size(), "forward_timed: op_ms too small");
+    ev.resize(h->ops.size() + 1);
+    for (auto& e : ev) RTPE_HIP_CHECK(hipEventCreate(&e));
+    RTPE_HIP_CHECK(hipEventRecord(ev[0], s));
+  }
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const OpState& o = h->ops[i];
+    const rtpe_op_desc& d = o.d;
+    int rc = RTPE_OK;
+    if (d.kind == RTPE_OP_STEM) {
+      const rtpe_tensor_desc& to = h->tensors[d.out_t];
+      StemArgs a;
+      a.x = x; a.x_f32 = x_dtype == RTPE_DTYPE_F32;
+      a.w = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[0]);
+      a.alpha = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
+      a.beta = a.alpha + 64;
+      a.y = tptr(d.out_t, d.out_coff);
+      a.N = N; a.H = H; a.W = W; a.out_ld = to.channels;
+      rc = stem_launch(a, s);
+    } else if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
+      const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+      const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
+      const bool dc = d.kind == RTPE_OP_DECONV;
+      const int Ho = dc ? Hi * 2 : Hi / d.stride, Wo = dc ? Wi * 2 : Wi / d.stride;
+      for (int k = 0; k < o.n_geom && rc == RTPE_OK; ++k) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = tptr(d.in_t, d.in_coff);
+        a.in_ld = ti.channels;
+        a.w = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[k]);
+        a.alpha = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
+        a.beta = a.alpha + o.plan[0].cout_pad;
+        if (d.res_t >= 0) { a.res = tptr(d.res_t, d.res_coff); a.res_ld = h->tensors[d.res_t].channels; }
+        if (!(d.flags & RTPE_F_NO_NHWC)) {
+          a.y = tptr(d.out_t, d.out_coff);
+          a.out_ld = h->tensors[d.out_t].channels;
+          // zero-padded channels up to the allocated row are written too (they
+          // are exact zeros: zero weights, zero affine) so that a consumer that
+          // reads the padded view sees finite data
+          int cs = o.plan[0].cout_pad;
+          const int room = h->tensors[d.out_t].channels - d.out_coff;
+          a.cout_store = cs < room ? cs : room;
+        }
+        if (d.flags & RTPE_F_OUT_PREDS) { a.y_nchw = preds; a.nchw_channels = d.cout; }
+        if (d.flags & RTPE_F_OUT_REFINED) { a.y_nchw = refined; a.nchw_channels = d.cout; }
+        a.nchw_f32 = out_dtype == RTPE_DTYPE_F32;
+        if (a.y_nchw == nullptr && (d.flags & (RTPE_F_OUT_PREDS | RTPE_F_OUT_REFINED))) {
+          set_error("forward: output pointer missing"); return RTPE_E_INVALID;
+        }
+        a.N = N; a.H_in = Hi; a.W_in = Wi;
+        a.H_full = Ho; a.W_full = Wo;
+        if (dc) {
+          a.H_pos = Hi; a.W_pos = Wi; a.o_mul = 2; a.oy_add = k >> 1; a.ox_add = k & 1;
+        } else {
+          a.H_pos = Ho; a.W_pos = Wo; a.o_mul = 1;
+        }
+        a.relu = (d.flags & RTPE_F_RELU) ? 1 : 0;
+        a.round_conv = (d.flags & RTPE_F_ROUND_CONV) ? 1 : 0;
+        const ConvTile tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos);
+        conv_fill_args(o.geom[k], o.plan[k], tile, &a);
+        rc = conv_launch(o.plan[k], tile, a, s);
+      }
+    } else {  // FUSE
+      const rtpe_tensor_desc& to = h->tensors[d.out_t];
+      FuseArgs a;
+      memset(&a, 0, sizeof(a));
+      a.n_terms = d.n_terms;
+      for (int t = 0; t < d.n_terms; ++t) {
+        a.term[t] = tptr(d.term_t[t], 0);
+        a.term_ld[t] = h->tensors[d.term_t[t]].channels;
+        a.term_up[t] = d.term_up[t];
+      }
+      a.y = tptr(d.out_t, d.out_coff);
+      a.out_ld = to.channels; a.C = d.cout;
+      a.N = N; a.H = H >> to.ds_log2; a.W = W >> to.ds_log2;
+      rc = fuse_launch(a, s);
+    }
+    if (rc != RTPE_OK) return rc;
+    if (timed) RTPE_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+  }
+  if (timed) {
+    RTPE_HIP_CHECK(hipEventSynchronize(ev.back()));
+    for (size_t i = 0; i < h->ops.size(); ++i) RTPE_HIP_CHECK(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) hipEventDestroy(e);
+  }
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_hrnet_forward(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H,
+                                  int32_t W, void* preds, void* refined, int32_t out_dtype, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  return run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes,
+             reinterpret_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+extern "C" int rtpe_hrnet_forward_timed(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H,
+                                        int32_t W, void* preds, void* refined, int32_t out_dtype,
+                                        void* workspace, size_t workspace_bytes, void* stream, float* op_ms,
+                                        int32_t n_ops) {
+  RTPE_REQUIRE(op_ms != nullptr, "forward_timed: op_ms is null");
+  return run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes,
+             reinterpret_cast<hipStream_t>(stream), op_ms, n_ops);
+}
+
+extern "C" int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W,
+                                  double* flops, double* bytes) {
+  RTPE_REQUIRE(h && op >= 0 && op < (int)h->ops.size() && flops && bytes, "op_cost: bad argument");
+  const rtpe_op_desc& d = h->ops[op].d;
+  *flops = 0; *bytes = 0;
+  if (d.kind == RTPE_OP_FUSE) {
+    const rtpe_tensor_desc& to = h->tensors[d.out_t];
+    const double px = (double)N * (H >> to.ds_log2) * (W >> to.ds_log2);
+    *bytes = px * d.cout * 2;
+    for (int t = 0; t < d.n_terms; ++t) *bytes += px / (double)(1 << (2 * d.term_up[t])) * d.cout * 2;
+    return RTPE_OK;
+  }
+  const int cin_logical = d.reserved[0] > 0 ? d.reserved[0] : d.cin;
+  if (d.kind == RTPE_OP_STEM) {
+    const double po = (double)N * (H / 2) * (W / 2);
+    *flops = 2.0 * po * 64 * 27;
+    *bytes = (double)N * 3 * H * W * 4 + po * 64 * 2;
+    return RTPE_OK;
+  }
+  const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+  const double pi = (double)N * (H >> ti.ds_log2) * (W >> ti.ds_log2);
+  const bool dc = d.kind == RTPE_OP_DECONV;
+  const double po = dc ? pi * 4 : pi / (d.stride * d.stride);
+  const double taps = dc ? 4 : d.ksize * d.ksize;
+  *flops = 2.0 * po * d.cout * cin_logical * taps;
+  *bytes = pi * cin_logical * 2 + po * d.cout * 2 + (d.res_t >= 0 ? po * d.cout * 2 : 0) +
+           (double)cin_logical * d.cout * d.ksize * d.ksize * 2;
+  return RTPE_OK;
+}
+
+// ---- single-layer entry (layer-level parity tests) -------------------------
+extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
+                                const void* w_host, const float* alpha_host, const float* beta_host,
+                                int32_t cout, int32_t ksize, int32_t stride, int32_t flags, const void* res,
+                                void* y, void* stream) {
+  RTPE_REQUIRE(x && w_host && alpha_host && beta_host && y, "conv2d_nhwc: null argument");
+  RTPE_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin % 8 == 0 && cout % 4 == 0,
+               "conv2d_nhwc: k=%d s=%d cin=%d cout=%d unsupported", ksize, stride, cin, cout);
+  RTPE_REQUIRE(H % stride == 0 && W % stride == 0, "conv2d_nhwc: H, W must be multiples of the stride");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ConvGeom g{cin, cout, ksize, stride, -1};
+  ConvPlan p = conv_make_plan(g);
+  std::vector<uint16_t> packed(p.packed_bytes / 2);
+  conv_pack_weights(g, p, reinterpret_cast<const uint16_t*>(w_host), packed.data());
+  std::vector<float> ab(2 * p.cout_pad, 0.f);
+  for (int c = 0; c < cout; ++c) { ab[c] = alpha_host[c]; ab[p.cout_pad + c] = beta_host[c]; }
+  char* dev = nullptr;
+  const size_t wb = align_up(p.packed_bytes, 256);
+  RTPE_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), wb + ab.size() * 4));
+  hipError_t e = hipMemcpy(dev, packed.data(), p.packed_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dev + wb, ab.data(), ab.size() * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(dev); return hip_fail(e, "hipMemcpy", __FILE__, __LINE__); }
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = reinterpret_cast<const _Float16*>(x); a.in_ld = cin;
+  a.w = reinterpret_cast<const _Float16*>(dev);
+  a.alpha = reinterpret_cast<const float*>(dev + wb); a.beta = a.alpha + p.cout_pad;
+  a.res = reinterpret_cast<const _Float16*>(res); a.res_ld = cout;
+  a.y = reinterpret_cast<_Float16*>(y); a.out_ld = cout; a.cout_store = cout;
+  a.N = N; a.H_in = H; a.W_in = W;
+  a.H_full = a.H_pos = H / stride; a.W_full = a.W_pos = W / stride; a.o_mul = 1;
+  a.relu = (flags & RTPE_F_RELU) ? 1 : 0;
+  a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
+  const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos);
+  conv_fill_args(g, p, tile, &a);
+  int rc = conv_launch(p, tile, a, s);
+  hipError_t es = hipStreamSynchronize(s);
+  hipFree(dev);
+  if (rc != RTPE_OK) return rc;
+  if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
+  return RTPE_OK;
+}

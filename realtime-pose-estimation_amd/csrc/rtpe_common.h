@@ -1,0 +1,129 @@
+// Internal helpers shared by the HIP translation units of librtpe_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "rtpe_hip.h"
+
+namespace rtpe {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define RTPE_HIP_CHECK(expr)                                               \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) return ::rtpe::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define RTPE_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::rtpe::set_error(__VA_ARGS__);           \
+      return RTPE_E_INVALID;                    \
+    }                                           \
+  } while (0)
+
+// exact unsigned division by a runtime constant: q = umulhi(n, mul) for
+// n * d < 2^32 (all uses here: n < 2^20, d < 2^12)
+struct FastDiv {
+  uint32_t d, mul;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.mul = d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+  return f.d <= 1 ? n : __umulhi(n, f.mul);
+}
+
+// ---- conv launch description (conv_mfma.hip) ------------------------------
+struct ConvArgs {
+  const _Float16* x;     // input view base (channel offset folded in)
+  const _Float16* w;     // packed weights for this layer (device)
+  const float* alpha;    // [cout_pad]
+  const float* beta;     // [cout_pad]
+  const _Float16* res;   // residual view base or nullptr
+  _Float16* y;           // NHWC output view base or nullptr
+  void* y_nchw;          // NCHW output (fp32 or fp16) or nullptr
+  int N, H_in, W_in, in_ld;
+  int H_pos, W_pos;      // grid of output positions computed by this launch
+  int H_full, W_full;    // full output spatial size (addressing)
+  int o_mul, oy_add, ox_add;  // output pixel = pos * o_mul + add
+  int in_mul;            // input base = pos * in_mul
+  int out_ld, res_ld;
+  int cin, cout;         // logical
+  int cout_store;        // channels written to NHWC (multiple of 4 groups masked)
+  int nchw_channels;     // channel count of the NCHW output
+  int nchw_f32;          // 1: fp32 NCHW, 0: fp16
+  int tapw, ntaps;       // taps form a tapw x tapw grid: (dy,dx) = (lo_y+ty, lo_x+tx)
+  int lo_y, lo_x;        // min tap offsets
+  int halo_h, halo_w;    // staged input tile (pixels)
+  int cc;                // input channels staged per chunk
+  int n_cchunks;         // ceil(cin / cc)
+  int kc;                // 32-wide k chunks per channel chunk = ceil(ntaps*cc/32)
+  int pstride;           // LDS bytes per staged pixel
+  int th, tw;            // output tile (positions); th*tw == 16*NT*WAVES
+  int tiles_x, tiles_y;
+  int relu, round_conv;
+  FastDiv div_tw, div_slots, div_rowslots, div_cc, div_tiles_x, div_tiles_xy;
+};
+
+struct ConvPlan {       // weight-layout half of the plan (fixed at create time)
+  int mt;               // cout tiles (x16) per wave = per workgroup
+  int cc, kc, n_cchunks, pstride;
+  int tapw, in_mul, lo_y, lo_x;
+  int cout_pad, n_cb;   // cout rounded up to 16*mt; number of cout blocks
+  size_t packed_bytes;  // bytes of packed weights (all cout blocks)
+};
+
+struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
+  int nt, waves;        // pixel tiles (x16) per wave, waves per workgroup
+  int th, tw;
+  size_t lds_bytes;
+};
+
+struct ConvGeom {       // logical layer, independent of the batch
+  int cin, cout, ksize, stride;
+  int deconv_class;     // -1: plain conv; 0..3: k4 s2 p1 transposed-conv parity class (a*2+b)
+};
+
+ConvPlan conv_make_plan(const ConvGeom& g);
+// choose the tile for a position grid (N images of H_pos x W_pos positions)
+ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos);
+// pack fp16 weights (host) into fragment order; w is OIHW (IOHW 4x4 for deconv classes)
+void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const uint16_t* w,
+                       uint16_t* packed);
+// fill geometry / divisors of `a` (pointers, sizes and flags are the caller's)
+void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, ConvArgs* a);
+int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+
+// ---- elementwise / stem (elementwise.hip) ---------------------------------
+struct FuseArgs {
+  const _Float16* term[4];
+  int term_ld[4], term_up[4];
+  int n_terms;
+  _Float16* y;
+  int out_ld, C;
+  int N, H, W;  // output spatial size
+};
+int fuse_launch(const FuseArgs& a, hipStream_t s);
+
+struct StemArgs {
+  const void* x;  // NCHW (N,3,H,W), fp32 or fp16
+  int x_f32;
+  const _Float16* w;  // [27][64] fp16, k = (ky*3+kx)*3 + c
+  const float* alpha;
+  const float* beta;
+  _Float16* y;  // NHWC (N,H/2,W/2,64)
+  int N, H, W, out_ld;
+};
+int stem_launch(const StemArgs& a, hipStream_t s);
+
+}  // namespace rtpe

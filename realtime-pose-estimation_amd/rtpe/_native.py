@@ -1,0 +1,114 @@
+"""ctypes binding of librtpe_hip.so (include/rtpe_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or
+cannot be loaded, importing anything that needs it raises with build
+instructions (``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "librtpe_hip.so")
+
+RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
+OP_STEM, OP_CONV, OP_DECONV, OP_FUSE = 0, 1, 2, 3
+F_RELU, F_ROUND_CONV, F_OUT_PREDS, F_OUT_REFINED, F_NO_NHWC = 1, 2, 4, 8, 16
+
+
+class TensorDesc(Structure):
+    _fields_ = [("channels", c_int32), ("ds_log2", c_int32), ("slot", c_int32), ("reserved", c_int32)]
+
+
+class OpDesc(Structure):
+    _fields_ = [("kind", c_int32), ("flags", c_int32),
+                ("in_t", c_int32), ("in_coff", c_int32),
+                ("out_t", c_int32), ("out_coff", c_int32),
+                ("res_t", c_int32), ("res_coff", c_int32),
+                ("cin", c_int32), ("cout", c_int32),
+                ("ksize", c_int32), ("stride", c_int32),
+                ("w_off", c_int64), ("ab_off", c_int64),
+                ("n_terms", c_int32), ("term_t", c_int32 * 4), ("term_up", c_int32 * 4),
+                ("reserved", c_int32 * 3)]
+
+
+_SIGS = {
+    "rtpe_last_error_string": (c_char_p, []),
+    "rtpe_version": (c_int32, []),
+    "rtpe_device_count": (c_int32, []),
+    "rtpe_hrnet_create": (c_int32, [POINTER(OpDesc), c_int32, POINTER(TensorDesc), c_int32,
+                                    c_void_p, c_size_t, c_int32, POINTER(c_void_p)]),
+    "rtpe_hrnet_destroy": (c_int32, [c_void_p]),
+    "rtpe_hrnet_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "rtpe_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "rtpe_hrnet_forward_timed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                           c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p,
+                                           POINTER(c_float), c_int32]),
+    "rtpe_hrnet_op_cost": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     POINTER(c_double), POINTER(c_double)]),
+    "rtpe_conv2d_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                   POINTER(c_float), POINTER(c_float), c_int32, c_int32, c_int32,
+                                   c_int32, c_void_p, c_void_p, c_void_p]),
+    "rtpe_bilinear_upsample": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32,
+                                         c_int32, c_void_p]),
+    "rtpe_nms": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "rtpe_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                            c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_size_t, c_void_p]),
+    "rtpe_topk_scratch_bytes": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "rtpe_topk_fused": (c_int32, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_int32, c_int32, c_int64,
+                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rtpe_match_by_tag": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_double, c_double, c_int32, c_int32, c_void_p, c_int32,
+                                    POINTER(c_int32)]),
+    "rtpe_munkres": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, POINTER(c_int32)]),
+    "rtpe_adjust_refine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                     c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "rtpe_adjust_refine_fused": (c_int32, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_int32, c_int32,
+                                           c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """the loaded library (raises if it has not been built)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "rtpe: %s not found - the HIP extension is not built and there is no CPU "
+                "fallback.  Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "from the repository root (needs hipcc)." % LIB_PATH)
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError("rtpe: cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)       # AttributeError if an export is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().rtpe_last_error_string()
+        raise RuntimeError("rtpe_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "rtpe: %s runs on the MI355X HIP path only and got a %s tensor; move it to a GPU "
+            "(there is deliberately no CPU fallback in the product path)" % (what, t.device))
+
+
+def stream_ptr(device):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

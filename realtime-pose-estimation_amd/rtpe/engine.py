@@ -1,0 +1,159 @@
+"""Inference loops of the hot path.
+
+``eval_student`` keeps the name and signature of the reference's
+``rtpe/engine.py:21-75``.  ``TeacherPipeline`` is the accelerated body of the
+per-image loops of ``validate_hhrnet.py:84-105`` / ``teacher_inference.py:67-90``:
+batched forward on the HIP executor + fused decode, one process per GPU, with
+the weights broadcast and the keypoints all-gathered over RCCL when a process
+group is active.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .third_party.group import HeatmapParser
+
+HM_PARSER_PARAMS = {"max_num_people": 30, "detection_threshold": 0.1, "tag_threshold": 1.0,
+                    "use_detection_val": True, "ignore_too_much": False, "tag_per_joint": True,
+                    "nms_ksize": 5, "nms_padding": 2}       # validate_hhrnet.py:40-47
+NUM_HEATMAPS = 17
+MAX_PEOPLE_RECORD = 30
+RECORD_FLOATS = 2 + MAX_PEOPLE_RECORD + MAX_PEOPLE_RECORD * NUM_HEATMAPS * 4   # 8,288 B
+
+
+def eval_student(model, hm_parser, val_dataloader, device,
+                 plot_every=None, save_every=None, save_dir="/tmp"):
+    """reference engine.py:21-75: run ``model`` over the loader, decode with
+    ``hm_parser.parse`` and return the dataset's evaluation dict.
+
+    Each batch is a tuple whose first two items are ``(img_id, img)``.  ``model``
+    may return one tensor (heatmaps in channels [:17], tags in [17:], as the
+    reference's students did) or the teacher's ``[preds, refined]`` list.
+    Plotting / image saving (``plot_every`` / ``save_every``) are not part of
+    the accelerated path and are ignored.
+    """
+    model.eval()
+    all_preds, all_scores = [], []
+    for batch_i, batch in enumerate(val_dataloader):
+        img = batch[1]
+        out_hw = tuple(img.shape[2:])
+        img = img.to(device)
+        with torch.no_grad():
+            try:
+                pred = model(img, out_hw)
+            except TypeError:
+                pred = model(img)
+        if isinstance(pred, (list, tuple)):
+            preds, refined = pred
+            res = hm_parser.parse_lowres(refined.float(), preds[:, NUM_HEATMAPS:].float(), out_hw)
+            grouped, scores = [res[0][0]], res[0][1]
+        else:
+            pred = pred.detach().float()
+            grouped, scores = hm_parser.parse(pred[:, :NUM_HEATMAPS], pred[:, NUM_HEATMAPS:].unsqueeze(-1),
+                                              adjust=True, refine=True)
+        all_preds.append([x for x in grouped[0] if x.size > 0])
+        all_scores.append(scores)
+    dataset = getattr(val_dataloader, "dataset", None)
+    if dataset is not None and hasattr(dataset, "evaluate"):
+        eval_dict, _ = dataset.evaluate(all_preds, all_scores, ".", False, False)
+        return eval_dict
+    return OrderedDict(images=len(all_preds), people=sum(len(p) for p in all_preds))
+
+
+def pack_records(image_ids, results, device):
+    """fixed-size keypoint records for the all-gather: per image
+    ``[image_index, n_people, scores[30], kpts[30][17][4]]`` as float32"""
+    rec = np.zeros((len(results), RECORD_FLOATS), np.float32)
+    for i, (img_id, (people, scores)) in enumerate(zip(image_ids, results)):
+        n = min(len(people) if people.ndim == 3 else 0, MAX_PEOPLE_RECORD)
+        rec[i, 0], rec[i, 1] = img_id, n
+        if n:
+            rec[i, 2:2 + n] = np.asarray(scores[:n], np.float32)
+            rec[i, 2 + MAX_PEOPLE_RECORD:2 + MAX_PEOPLE_RECORD + n * NUM_HEATMAPS * 4] = \
+                people[:n, :, :4].reshape(-1)
+    return torch.from_numpy(rec).to(device)
+
+
+def unpack_records(rec):
+    out = {}
+    for r in rec.cpu().numpy():
+        n = int(r[1])
+        kp = r[2 + MAX_PEOPLE_RECORD:2 + MAX_PEOPLE_RECORD + n * NUM_HEATMAPS * 4]
+        out[int(r[0])] = (kp.reshape(n, NUM_HEATMAPS, 4).copy(), r[2:2 + n].copy())
+    return out
+
+
+class TeacherPipeline:
+    """forward + decode for batches of pre-processed images on one GPU."""
+
+    def __init__(self, model, parser=None, device=None):
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.model = model.to(self.device).eval()
+        self.parser = parser or HeatmapParser(num_joints=NUM_HEATMAPS, **HM_PARSER_PARAMS)
+
+    @torch.no_grad()
+    def forward(self, images):
+        return self.model(images)
+
+    @torch.no_grad()
+    def __call__(self, images, out_hw=None):
+        """images (N,3,H,W) on the GPU -> list of (people, scores) per image;
+        out_hw = decode resolution (original image size), default (H, W)."""
+        preds, refined = self.model(images)
+        hw = tuple(out_hw) if out_hw is not None else tuple(images.shape[2:])
+        return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
+
+    def gather(self, image_ids, results):
+        """all-gather of the decoded keypoints over the process group (RCCL)"""
+        import torch.distributed as dist
+        rec = pack_records(image_ids, results, self.device)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return rec
+        return all_gather_records(rec)
+
+
+def all_gather_records(rec):
+    """variable count per rank: pad to the max, gather, strip the padding"""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    m = int(max(int(c.item()) for c in counts))
+    pad = torch.zeros((m, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    pad[:rec.shape[0]] = rec
+    out = torch.empty((world * m, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, pad)
+    keep = [out[r * m:r * m + int(counts[r].item())] for r in range(world)]
+    return torch.cat(keep)
+
+
+def shard_indices(n_items, rank, world):
+    """contiguous blocks, sizes differing by at most one (100 images over 8 ranks
+    -> 13,13,13,13,12,12,12,12)"""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def broadcast_state_dict(sd, src=0, device=None):
+    """rank ``src`` holds the checkpoint; every rank gets the tensors over
+    RCCL as ONE packed buffer per dtype."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    keys = sorted(sd.keys())
+    out = {}
+    for dt in (torch.float32, torch.float16, torch.int64):
+        ks = [k for k in keys if sd[k].dtype == dt]
+        if not ks:
+            continue
+        flat = torch.cat([sd[k].reshape(-1) for k in ks]).to(device)
+        dist.broadcast(flat, src)
+        o = 0
+        for k in ks:
+            n = sd[k].numel()
+            out[k] = flat[o:o + n].reshape(sd[k].shape).cpu()
+            o += n
+    return out

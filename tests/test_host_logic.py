@@ -1,0 +1,187 @@
+"""CPU-side tests of the product: state-dict contract, program compiler, C-ABI
+exports, the host matcher (C++), sharding / record packing, and the N>1 path
+over gloo.  No GPU, no compute kernels."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_ref, hungarian_ref, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from rtpe import _native
+    return _native
+
+
+def test_abi_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "rtpe_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rtpe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    lib = built.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(built.EXPORTS)
+    assert lib.rtpe_version() >= 1
+    assert lib.rtpe_device_count() >= 0
+
+
+def test_state_dict_contract_of_product_module(w48_shapes):
+    from rtpe.helpers import build_hrnet_w48_teacher
+    m = build_hrnet_w48_teacher()
+    sd = m.state_dict()
+    assert list(sd.keys()) == ["1." + k for k in w48_shapes]          # same names, same order
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {"1." + k: v for k, v in w48_shapes.items()}
+    # half wrapper: conv weights fp16, BatchNorm fp32 (fp16util.py:71-91 of the reference)
+    assert sd["1.conv1.weight"].dtype == torch.float16
+    assert sd["1.bn1.weight"].dtype == torch.float32 and sd["1.bn1.running_var"].dtype == torch.float32
+    assert sd["1.final_layers.0.bias"].dtype == torch.float16
+    # strict load of a checkpoint-shaped dict works and missing keys fail
+    ck = {"1." + k: v for k, v in synth.make_state_dict(w48_shapes, 0, "W1").items()}
+    m.load_state_dict(ck, strict=True)
+    ck.pop("1.conv1.weight")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(ck, strict=True)
+    assert m[1].__class__.__name__ == "PoseHigherResolutionNet"       # callers index [1]
+
+
+def test_program_compiles_to_fused_ops(built):
+    from rtpe.helpers import build_hrnet_w48_teacher
+    prog = build_hrnet_w48_teacher()[1].compile_program()
+    kinds = [op.kind for op in prog.ops]
+    assert kinds.count(built.OP_STEM) == 1 and kinds.count(built.OP_DECONV) == 1
+    # 302 Conv2d of the reference = 1 stem + 301 conv ops; 1 ConvTranspose2d; 23 fuse sums
+    assert kinds.count(built.OP_CONV) == 301
+    assert kinds.count(built.OP_FUSE) == 23
+    assert prog.n_preds == 34 and prog.n_refined == 17
+    assert len(prog.blob) > 127e6                         # 63.9 M fp16 weights + affine
+    # lifetimes: at every op its input, residual and output live in different slots
+    for op in prog.ops:
+        if op.kind == built.OP_CONV and op.out_t >= 0 and op.out_t != op.in_t:
+            slots = {prog.tensors[op.in_t].slot, prog.tensors[op.out_t].slot}
+            assert len(slots) == 2
+            if op.res_t >= 0:
+                assert prog.tensors[op.res_t].slot != prog.tensors[op.out_t].slot
+
+
+def test_no_cpu_fallback(built):
+    from rtpe.helpers import build_hrnet_w48_teacher
+    from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+    m = build_hrnet_w48_teacher()
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        m[1](torch.zeros(1, 3, 64, 64).half())
+    assert PoseHigherResolutionNet(s2_modules=1).conv1.weight.dtype == torch.float32
+    if not torch.cuda.is_available():
+        from rtpe.third_party.group import HeatmapParser
+        hp = HeatmapParser(17, 30, 0.1, 1.0, True, False)
+        with pytest.raises(RuntimeError):
+            hp.parse(torch.zeros(1, 17, 32, 32), torch.zeros(1, 17, 32, 32, 1))
+
+
+def test_munkres_cpp_equals_restatement(built):
+    from rtpe.third_party.group import py_max_match
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a, g = int(rng.integers(1, 31)), int(rng.integers(1, 31))
+        # tie-heavy costs as group.py:66 builds them
+        c = np.round(rng.random((a, g)) * 4) * 100 - rng.random((a, 1))
+        if a > g:
+            c = np.concatenate((c, np.full((a, a - g), 1e10)), 1)
+        want = hungarian_ref.munkres_compute(c)
+        got = [tuple(int(v) for v in p) for p in py_max_match(c)]
+        assert got == want
+    for n in (1, 2, 7):
+        c = rng.random((n, n + 2))
+        assert [tuple(p) for p in py_max_match(c)] == hungarian_ref.munkres_compute(c)
+
+
+@pytest.mark.parametrize("name", ["p0", "p1", "p3", "p10", "p30", "p3_480", "p5_d2", "p40"])
+def test_match_by_tag_cpp_matches_golden(built, golden_dir, name):
+    from rtpe.third_party.group import HeatmapParser, Params, match_by_tag
+    g = np.load(os.path.join(golden_dir, "decode_%s.npz" % name))
+    params = Params(17, 30, 0.1, 1.0, True, False)
+    got = match_by_tag((g["tag_k"][0], g["loc_k"][0], g["val_k"][0]), params)
+    want = g["matched"]
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    hp = HeatmapParser(17, 30, 0.1, 1.0, True, False)
+    np.testing.assert_array_equal(hp.match(g["tag_k"], g["loc_k"], g["val_k"])[0], want)
+
+
+def test_match_by_tag_variants_against_oracle(built):
+    from rtpe.third_party.group import Params, match_by_tag
+    rng = np.random.default_rng(9)
+    for trial in range(40):
+        D = int(rng.choice([1, 1, 2, 9]))
+        J, K = 17, 30
+        val = np.sort(rng.random((J, K)).astype(np.float32) * (0.3 if trial % 3 else 1.0), axis=1)[:, ::-1]
+        loc = rng.integers(0, 640, (J, K, 2)).astype(np.int64)
+        tag = (rng.integers(0, 6, (J, K, D)) * 1.5 + rng.normal(0, 0.3, (J, K, D))).astype(np.float32)
+        for kw in (dict(), dict(use_detection_val=False), dict(ignore_too_much=True, max_num_people=5),
+                   dict(max_num_people=8)):
+            a = dict(num_joints=J, max_num_people=30, detection_threshold=0.1, tag_threshold=1.0,
+                     use_detection_val=True, ignore_too_much=False)
+            a.update(kw)
+            want = decode_ref.match_by_tag(tag, loc, np.ascontiguousarray(val), decode_ref.Params(**a))
+            got = match_by_tag((tag, loc, np.ascontiguousarray(val)), Params(**a))
+            assert got.shape == want.shape
+            np.testing.assert_array_equal(got, want)
+
+
+def test_sharding_and_records():
+    from rtpe import engine
+    assert [len(engine.shard_indices(100, r, 8)) for r in range(8)] == [13, 13, 13, 13, 12, 12, 12, 12]
+    assert sum((engine.shard_indices(100, r, 8) for r in range(8)), []) == list(range(100))
+    assert engine.RECORD_FLOATS * 4 == 8288                     # SURVEY.md section 8e record
+    people = np.arange(2 * 17 * 4, dtype=np.float32).reshape(2, 17, 4)
+    rec = engine.pack_records([7, 9], [(people, [0.5, 0.25]), (np.array([], np.float32), [])], "cpu")
+    back = engine.unpack_records(rec)
+    np.testing.assert_array_equal(back[7][0], people)
+    np.testing.assert_array_equal(back[7][1], np.array([0.5, 0.25], np.float32))
+    assert back[9][0].shape == (0, 17, 4)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtpe import engine
+    ids = engine.shard_indices(5, rank, world)                  # 3 + 2 images
+    res = [(np.full((1, 17, 4), float(i), np.float32), [float(i)]) for i in ids]
+    rec = engine.pack_records(ids, res, "cpu")
+    allrec = engine.all_gather_records(rec)
+    sd = {"a": torch.arange(6.).reshape(2, 3) * (1 if rank == 0 else 0),
+          "b": (torch.ones(4) * (3 if rank == 0 else 0)).half(),
+          "n": torch.tensor(5 if rank == 0 else 0)}
+    sd = engine.broadcast_state_dict(sd, 0, "cpu")
+    out = engine.unpack_records(allrec)
+    q.put((rank, sorted(out.keys()), [float(out[i][0][0, 0, 0]) for i in sorted(out)],
+           sd["a"].tolist(), sd["b"].tolist(), int(sd["n"])))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_weight_broadcast_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, keys, vals, a, b, n in got:
+        assert keys == [0, 1, 2, 3, 4] and vals == [0., 1., 2., 3., 4.]
+        assert a == [[0., 1., 2.], [3., 4., 5.]] and b == [3.] * 4 and n == 5
