@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: HigherHRNet-w48 forward + heatmap->keypoint decode
+at 640x640 on N MI355X (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole path over one batch per GPU: forward (half
+wrapper numerics, fp32 NCHW in/out) -> fused bilinear+NMS+top-k -> host
+match_by_tag -> adjust/refine -> fixed-size keypoint records all-gathered over
+the process group.  Inputs are synthetic and resident in HBM before the timed
+region; weights are seeded random (no checkpoint / dataset is reachable).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFS = 2500.0       # dense fp16/bf16 MFMA
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--weights", default="W0", choices=["W0", "W1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--dump-ops", default="", help="write the per-op table to this file")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from oracle import synth
+    from rtpe import engine
+    from rtpe.helpers import build_hrnet_w48_teacher
+
+    # ---- weights: rank 0 builds them, everyone gets them over RCCL ------------
+    with open(os.path.join(ROOT, "tests", "golden", "w48_shapes.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+    sd = synth.make_state_dict(shapes, 0, args.weights) if rank == 0 else \
+        {k: torch.zeros(v, dtype=torch.long if k.endswith("num_batches_tracked") else torch.float32)
+         for k, v in shapes.items()}
+    sd = engine.broadcast_state_dict(sd, 0, dev)
+    model = build_hrnet_w48_teacher({"1." + k: v for k, v in sd.items()})
+    pipe = engine.TeacherPipeline(model, device=dev)
+    eng = model[1]._engine(dev)
+
+    B, S = args.batch, args.size
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x = torch.randn(B, 3, S, S, generator=g, device=dev)
+    ids = [rank * B + i for i in range(B)]
+    n_ops = len(eng.program.ops)
+    op_ms = np.zeros(n_ops)
+    people = [0]
+
+    def step(timed):
+        if timed:
+            (preds, refined), ms = eng.forward_timed(x)
+            op_ms[:] += np.asarray(ms)
+        else:
+            preds, refined = eng.forward(x)
+        res = pipe.parser.parse_lowres(refined, preds[:, engine.NUM_HEATMAPS:], (S, S))
+        people[0] = sum(len(p) if p.ndim == 3 else 0 for p, _ in res)
+        return pipe.gather(ids, res)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # forward-only and decode-only rates (outside the timed region, for the record)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(max(2, args.steps // 2)):
+        eng.forward(x)
+    torch.cuda.synchronize(dev)
+    fwd_s = (time.perf_counter() - t1) / max(2, args.steps // 2)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel --------------------------------------
+    op_ms /= max(1, args.steps)
+    names = eng.program.names
+    costs = [eng.op_cost(i, B, S, S) for i in range(n_ops)]
+    by_name = {}
+    for i, nm in enumerate(names):
+        d = by_name.setdefault(nm, dict(n=0, ms=0.0, flops=0.0, bytes=0.0, res={}))
+        d["n"] += 1
+        d["ms"] += op_ms[i]
+        d["flops"] += costs[i][0]
+        d["bytes"] += costs[i][1]
+    # dominant = the fused 3x3 C=48 BasicBlock conv at 160x160 (64 launches / forward)
+    dom_idx = [i for i, nm in enumerate(names) if nm.startswith("conv 48->48 k3s1")
+               and eng.program.tensors[eng.program.ops[i].out_t].ds_log2 == 2]
+    dom_ms = float(np.mean([op_ms[i] for i in dom_idx]))
+    dom_bytes = float(np.mean([costs[i][1] for i in dom_idx]))
+    dom_flops = float(np.mean([costs[i][0] for i in dom_idx]))
+    total_flops = sum(c[0] for c in costs)
+    total_bytes = sum(c[1] for c in costs)
+    fwd_ms_events = float(op_ms.sum())
+    roofline = {
+        "kernel": "conv_mfma_kernel<3,*,4> 3x3 s1 48->48 @160x160 (BasicBlock conv, %d launches/forward)" % len(dom_idx),
+        "bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+        "launch_us": round(dom_ms * 1e3, 2), "bytes_per_launch": dom_bytes,
+        "mfma_tflops": round(dom_flops / (dom_ms * 1e-3) / 1e12, 1),
+        "forward_tflops": round(total_flops / (fwd_ms_events * 1e-3) / 1e12, 1),
+        "forward_mfma_frac": round(total_flops / (fwd_ms_events * 1e-3) / 1e12 / MFMA_PEAK_TFS, 4),
+        "forward_hbm_gbs": round(total_bytes / (fwd_ms_events * 1e-3) / 1e9, 1),
+    }
+    if args.dump_ops:
+        with open(args.dump_ops, "w") as f:
+            f.write("# per-op-class HIP-event times, batch %d, %dx%d, avg over %d steps\n" % (B, S, S, args.steps))
+            f.write("%-34s %4s %9s %9s %9s %8s\n" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op"))
+            for nm, d in sorted(by_name.items(), key=lambda kv: -kv[1]["ms"]):
+                f.write("%-34s %4d %9.3f %9.1f %9.1f %8.1f\n" % (
+                    nm, d["n"], d["ms"], d["flops"] / max(d["ms"], 1e-9) / 1e9,
+                    d["bytes"] / max(d["ms"], 1e-9) / 1e6, d["ms"] / d["n"] * 1e3))
+            f.write("forward total (events) %.3f ms; wall %.3f ms\n" % (fwd_ms_events, fwd_s * 1e3))
+
+    # ---- CPU baseline: the oracle (a port of the reference path) on the host cores
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import decode_ref, hrnet_ref
+        # the GPU box gives one GPU a share of the host: use the cores we are allowed
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(cores, 16))
+        torch.set_num_threads(cores)
+        print("cpu baseline: oracle on %d threads ..." % cores, file=sys.stderr, flush=True)
+        net = hrnet_ref.OracleNet(sd, half=True)
+        xc = x[:args.cpu_images].cpu()
+        net(xc[:1])                                          # warm-up
+        c0 = time.perf_counter()
+        n_done = 0
+        for i in range(args.cpu_images):
+            p, r = net(xc[i:i + 1])
+            hms = decode_ref.upsample_bilinear(r, S, S)
+            aes = decode_ref.upsample_bilinear(p[:, 17:], S, S)
+            decode_ref.HeatmapParserRef().parse(hms, aes.unsqueeze(-1))
+            n_done += 1
+            print("cpu baseline: image %d done at %.1f s" % (n_done, time.perf_counter() - c0), file=sys.stderr,
+                  flush=True)
+            if time.perf_counter() - c0 > 40:
+                break
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(n_done / cdt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+               "sample": "%d image(s) of the same synthetic batch, forward (half wrapper) + bilinear + parse, "
+                         "oracle/ on torch CPU with %d threads" % (n_done, cores)}
+
+    value = world * B * args.steps / dt
+    out = {
+        "metric": "images/sec at 640x640 (HRNet-w48 fwd+decode)", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16 (fp32 accumulate, fp32 BatchNorm; fp32 NCHW in/out)",
+        "data": "synthetic",
+        "config": {"workload": "configs[2]: batch=%d per GPU, %dx%d, half-wrapper teacher forward + decode of "
+                               "17 keypoint channels, weights %s (seeded random)" % (B, S, S, args.weights),
+                   "batch_per_gpu": B, "people_per_batch_rank0": people[0],
+                   "forward_only_images_per_sec_per_gpu": round(B / fwd_s, 1)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

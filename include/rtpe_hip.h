@@ -211,24 +211,40 @@ int rtpe_match_by_tag(const float* tag_k, const int32_t* ind_k, const float* val
 int rtpe_munkres(const double* cost, int32_t nr, int32_t nc, int32_t* pairs, int32_t* n_pairs);
 
 /* HeatmapParser.adjust (group.py:181-200) + .refine (group.py:202-264) on
- * the GPU for P persons (of possibly several images).  det (planes,h,w) f32,
- * tag (planes,h,w,D) f32 device maps with planes = N*J; ans_in (P,J,3+D) f32
- * device is read, ans_out (same shape, a different buffer) is written: every
- * detected joint is adjusted (if do_adjust), every undetected one is searched
- * for by the tag-penalised arg-max (if do_refine), the rest is copied.  person_img (P) i32 device = image index of each person (NULL:
- * all image 0).  scores (P) f32 device = mean val per person before refine
- * (group.py:272); may be NULL. */
-int rtpe_adjust_refine(const float* det, const float* tag, int32_t J, int32_t h, int32_t w,
+ * the GPU for P persons of N images.  det (N*J,h,w) f32, tag (N*J,h,w,D) f32
+ * device maps; ans_in (P,J,3+D) f32 device is read, ans_out (same shape, a
+ * different buffer) is written: every detected joint is adjusted (if
+ * do_adjust), every undetected one is searched for by the tag-penalised
+ * arg-max (if do_refine), the rest is copied.  person_img (P) i32 device =
+ * image index of each person, ascending (NULL: all image 0).  scores (P) f32
+ * device = mean val per person before refine (group.py:272); may be NULL.
+ * scratch: device, rtpe_adjust_refine_scratch_bytes(). */
+int rtpe_adjust_refine(const float* det, const float* tag, int32_t N, int32_t J, int32_t h, int32_t w,
                        int32_t D, const float* ans_in, float* ans_out, const int32_t* person_img,
-                       int32_t P, int32_t do_adjust, int32_t do_refine, float* scores, void* stream);
+                       int32_t P, int32_t do_adjust, int32_t do_refine, float* scores,
+                       void* scratch, size_t scratch_bytes, void* stream);
+int rtpe_adjust_refine_scratch_bytes(int32_t P, int32_t J, int32_t D, size_t* bytes);
 
 /* Fused variant working from the low-res maps (bilinear evaluated on the fly,
  * D = 1; addressing as in rtpe_topk_fused). */
 int rtpe_adjust_refine_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
                              const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride,
-                             int32_t J, int32_t oh, int32_t ow,
+                             int32_t N, int32_t J, int32_t oh, int32_t ow,
                              const float* ans_in, float* ans_out, const int32_t* person_img, int32_t P,
-                             int32_t do_adjust, int32_t do_refine, float* scores, void* stream);
+                             int32_t do_adjust, int32_t do_refine, float* scores,
+                             void* scratch, size_t scratch_bytes, void* stream);
+
+/* match_by_tag for a batch of N images on `n_threads` host threads.  Inputs as
+ * rtpe_match_by_tag with a leading image axis.  People of image n follow those
+ * of image n-1 in `ans` (max_people_total rows of (J,3+D)); person_img[i] =
+ * image of row i; counts[n] = people found in image n (all of them are
+ * counted, rows beyond max_people_total are dropped).  HOST function. */
+int rtpe_match_by_tag_batch(const float* tag_k, const int32_t* ind_k, const float* val_k,
+                            int32_t N, int32_t J, int32_t K, int32_t D, int32_t w,
+                            int32_t max_num_people, double detection_threshold,
+                            double tag_threshold, int32_t use_detection_val,
+                            int32_t ignore_too_much, float* ans, int32_t max_people_total,
+                            int32_t* person_img, int32_t* counts, int32_t n_threads);
 
 #ifdef __cplusplus
 }

@@ -314,34 +314,25 @@ __device__ __forceinline__ float pairwise8_sum(const float* a, int n) {   // num
 }
 
 constexpr int kMaxJ = 32, kMaxD = 32;
+constexpr int kRefineGroup = 16;     // people handled per pass over the pixels
+constexpr int kRefineStripes = 10;   // row stripes per (image, joint) map
 
-template <class Map, class TagMap>
-__global__ void __launch_bounds__(256) adjust_refine_kernel(Map m, TagMap tm, int J, int h, int w, int D,
+// (1) one block per person: copy rows, adjust detected joints (group.py:181-200),
+//     mean tag of the detected joints (group.py:214-222), score (group.py:272)
+template <class Map>
+__global__ void __launch_bounds__(64) adjust_prepare_kernel(Map m, int J, int h, int w, int D,
                                                             const float* ans_in, float* ans_out,
                                                             const int* person_img, int do_adjust,
-                                                            int do_refine, float* scores) {
-  // Block (p, j) reads the person's rows only from ans_in (the state before any
-  // fill, as group.py:214-222 collects the tags first) and owns row (p, j) of
-  // ans_out.
-  __shared__ u64 red[4];
-  __shared__ float mean_tag[kMaxD];
-  const int p = blockIdx.x / J, j = blockIdx.x - p * J;
-  const int img = person_img ? person_img[p] : 0;
-  const int plane = img * J + j;
+                                                            float* scores, float* mean_tag) {
+  const int p = blockIdx.x, j = threadIdx.x;
   const int row_len = 3 + D;
   const float* kp = ans_in + (size_t)p * J * row_len;
-  float* out = ans_out + ((size_t)p * J + j) * row_len;
-  const float val = kp[j * row_len + 2];
-  if (threadIdx.x < row_len) out[threadIdx.x] = kp[j * row_len + threadIdx.x];
-  __syncthreads();
-
-  if (threadIdx.x == 0 && j == 0 && scores) {           // group.py:272 (before refine)
-    float v[kMaxJ];
-    for (int q = 0; q < J; ++q) v[q] = kp[q * row_len + 2];
-    scores[p] = pairwise8_sum(v, J) / (float)J;
-  }
-  if (val > 0.f) {                                        // adjust, group.py:181-200
-    if (do_adjust && threadIdx.x == 0) {
+  const int img = person_img ? person_img[p] : 0;
+  if (j < J) {
+    float* out = ans_out + ((size_t)p * J + j) * row_len;
+    for (int c = 0; c < row_len; ++c) out[c] = kp[j * row_len + c];
+    if (do_adjust && kp[j * row_len + 2] > 0.f) {
+      const int plane = img * J + j;
       float cx = kp[j * row_len + 0], cy = kp[j * row_len + 1];
       const int col = (int)cx, row = (int)cy;
       const int cr = col + 1 < w - 1 ? col + 1 : w - 1, cl = col - 1 > 0 ? col - 1 : 0;
@@ -351,68 +342,183 @@ __global__ void __launch_bounds__(256) adjust_refine_kernel(Map m, TagMap tm, in
       out[0] = cx + 0.5f;
       out[1] = cy + 0.5f;
     }
-    return;
   }
-  if (!do_refine || val != 0.f) return;                   // refine fills joints with val == 0 only
-
-  // mean tag of the detected joints (the tags stored in ans are tag[j, y, x]), group.py:214-222
-  if (threadIdx.x < D) {
-    const int d = threadIdx.x;
-    float t[kMaxJ];
-    int n = 0;
-    for (int q = 0; q < J; ++q)
-      if (kp[q * row_len + 2] > 0.f) t[n++] = kp[q * row_len + 3 + d];
-    float s;
-    if (D == 1) {
-      s = pairwise8_sum(t, n);
-    } else {
-      s = 0.f;
-      for (int i = 0; i < n; ++i) s = s + t[i];
+  if (j == 0) {
+    float v[kMaxJ];
+    if (scores) {
+      for (int q = 0; q < J; ++q) v[q] = kp[q * row_len + 2];
+      scores[p] = pairwise8_sum(v, J) / (float)J;
     }
-    mean_tag[d] = s / (float)n;
+    for (int d = 0; d < D; ++d) {
+      int n = 0;
+      for (int q = 0; q < J; ++q)
+        if (kp[q * row_len + 2] > 0.f) v[n++] = kp[q * row_len + 3 + d];
+      float s;
+      if (D == 1) {
+        s = pairwise8_sum(v, n);
+      } else {
+        s = 0.f;
+        for (int i = 0; i < n; ++i) s = s + v[i];
+      }
+      mean_tag[(size_t)p * D + d] = s / (float)n;
+    }
+  }
+}
+
+// (2) one block per (image, joint, row stripe): every person of the image that
+//     misses this joint is scored against every pixel of the stripe; the map is
+//     sampled once per pixel for all of them.  arg-max keys are merged with
+//     atomicMax (value bits << 32 | ~index: the first maximum wins, as np.argmax)
+template <class Map, class TagMap>
+__global__ void __launch_bounds__(256) refine_scan_kernel(Map m, TagMap tm, int J, int h, int w, int D,
+                                                          const float* ans_in, const int* person_img, int P,
+                                                          const float* mean_tag, u64* best_key) {
+  __shared__ int lo_hi[2];
+  __shared__ int n_need;
+  __shared__ int need[512];
+  __shared__ u64 red[kRefineGroup];
+  __shared__ float gmean[kRefineGroup * kMaxD];
+  const int plane = blockIdx.y, img = plane / J, j = plane - img * J;
+  const int row_len = 3 + D;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = P;                      // persons are sorted by image: [lo, hi) = this image
+    if (person_img) {
+      int a = 0, b = P;
+      while (a < b) { const int c = (a + b) >> 1; if (person_img[c] < img) a = c + 1; else b = c; }
+      lo = a; b = P;
+      while (a < b) { const int c = (a + b) >> 1; if (person_img[c] <= img) a = c + 1; else b = c; }
+      hi = a;
+    } else if (img != 0) {
+      hi = 0;
+    }
+    lo_hi[0] = lo; lo_hi[1] = hi;
+    n_need = 0;
   }
   __syncthreads();
+  const int lo = lo_hi[0], hi = lo_hi[1];
+  const int rows = (h + gridDim.x - 1) / gridDim.x;
+  const int y_begin = blockIdx.x * rows, y_end = min(h, y_begin + rows);
+  if (y_begin >= y_end) return;
+  const int npix = (y_end - y_begin) * w;
+  for (int base = lo; base < hi; base += 512) {          // people needing joint j, 512 at a time
+    __syncthreads();
+    if (threadIdx.x == 0) n_need = 0;
+    __syncthreads();
+    for (int p = base + threadIdx.x; p < min(hi, base + 512); p += 256)
+      if (ans_in[((size_t)p * J + j) * row_len + 2] == 0.f) need[atomicAdd(&n_need, 1)] = p;
+    __syncthreads();
+    const int nn = n_need;
+    for (int g0 = 0; g0 < nn; g0 += kRefineGroup) {
+      const int gn = min(kRefineGroup, nn - g0);
+      __syncthreads();
+      if (threadIdx.x < kRefineGroup) red[threadIdx.x] = 0;
+      for (int i = threadIdx.x; i < gn * D; i += 256)
+        gmean[(i / D) * kMaxD + i % D] = mean_tag[(size_t)need[g0 + i / D] * D + i % D];
+      __syncthreads();
+      u64 best[kRefineGroup];
+#pragma unroll
+      for (int q = 0; q < kRefineGroup; ++q) best[q] = 0;
+      for (int i = threadIdx.x; i < npix; i += 256) {
+        const int yy = i / w, x = i - yy * w, y = y_begin + yy;
+        const float dv = m.at(plane, y, x);
+        const unsigned nidx = 0xffffffffu - (unsigned)(y * w + x);
+        if (D == 1) {
+          const float tv = tm.at(plane, y, x, 0);
+#pragma unroll
+          for (int q = 0; q < kRefineGroup; ++q) {
+            if (q < gn) {
+              const float d0 = tv - gmean[q * kMaxD];
+              const float score = dv - rintf(sqrtf(d0 * d0));
+              const u64 key = ((u64)order_bits(score) << 32) | nidx;
+              best[q] = key > best[q] ? key : best[q];
+            }
+          }
+        } else {
+          float tv[kMaxD];
+          for (int d = 0; d < D; ++d) tv[d] = tm.at(plane, y, x, d);
+#pragma unroll
+          for (int q = 0; q < kRefineGroup; ++q) {
+            if (q < gn) {
+              float ss;
+              if (D < 8) {
+                const float d0 = tv[0] - gmean[q * kMaxD];
+                ss = d0 * d0;
+                for (int d = 1; d < D; ++d) { const float dd = tv[d] - gmean[q * kMaxD + d]; ss = ss + dd * dd; }
+              } else {
+                float sq[kMaxD];
+                for (int d = 0; d < D; ++d) { const float dd = tv[d] - gmean[q * kMaxD + d]; sq[d] = dd * dd; }
+                ss = pairwise8_sum(sq, D);
+              }
+              const float score = dv - rintf(sqrtf(ss));
+              const u64 key = ((u64)order_bits(score) << 32) | nidx;
+              best[q] = key > best[q] ? key : best[q];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kRefineGroup; ++q) {
+        if (q < gn) {
+          const u64 k = wave_max(best[q]);
+          if ((threadIdx.x & 63) == 0) atomicMax(&red[q], k);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < gn)
+        atomicMax(&best_key[(size_t)need[g0 + threadIdx.x] * J + j], red[threadIdx.x]);
+    }
+  }
+}
 
-  // arg-max over the whole map of det - round(||tag - mean||), group.py:225-233
-  u64 best = 0;
-  const int total = h * w;
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int y = i / w, x = i - y * w;
-    float ss;
-    if (D < 8) {
-      float d0 = tm.at(plane, y, x, 0) - mean_tag[0];
-      ss = d0 * d0;
-      for (int d = 1; d < D; ++d) {
-        const float dd = tm.at(plane, y, x, d) - mean_tag[d];
-        ss = ss + dd * dd;
-      }
-    } else {
-      float sq[kMaxD];
-      for (int d = 0; d < D; ++d) {
-        const float dd = tm.at(plane, y, x, d) - mean_tag[d];
-        sq[d] = dd * dd;
-      }
-      ss = pairwise8_sum(sq, D);
-    }
-    const float score = m.at(plane, y, x) - rintf(sqrtf(ss));
-    const u64 key = make_key(score, (unsigned)i);
-    best = key > best ? key : best;
+// (3) fill the joints that were missing and whose arg-max has a positive value (group.py:233-262)
+template <class Map>
+__global__ void __launch_bounds__(256) refine_finalize_kernel(Map m, int J, int h, int w, int D,
+                                                              const float* ans_in, float* ans_out,
+                                                              const int* person_img, int P, const u64* best_key) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P * J) return;
+  const int p = i / J, j = i - p * J;
+  const int row_len = 3 + D;
+  if (ans_in[(size_t)i * row_len + 2] != 0.f) return;
+  const u64 key = best_key[i];
+  if (key == 0) return;
+  const int plane = (person_img ? person_img[p] : 0) * J + j;
+  const int idx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+  const int y = idx / w, x = idx - y * w;
+  const float v = m.at(plane, y, x);
+  if (v > 0.f) {
+    const int xr = x + 1 < w - 1 ? x + 1 : w - 1, xl = x - 1 > 0 ? x - 1 : 0;
+    const int yd = y + 1 < h - 1 ? y + 1 : h - 1, yu = y - 1 > 0 ? y - 1 : 0;
+    float* out = ans_out + (size_t)i * row_len;
+    out[0] = (float)x + 0.5f + (m.at(plane, y, xr) > m.at(plane, y, xl) ? 0.25f : -0.25f);
+    out[1] = (float)y + 0.5f + (m.at(plane, yd, x) > m.at(plane, yu, x) ? 0.25f : -0.25f);
+    out[2] = v;
   }
-  best = block_max(best, red);
-  if (threadIdx.x == 0) {
-    const int idx = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
-    const int y = idx / w, x = idx - y * w;
-    const float v = m.at(plane, y, x);
-    if (v > 0.f) {                                        // group.py:256-262
-      const int xr = x + 1 < w - 1 ? x + 1 : w - 1, xl = x - 1 > 0 ? x - 1 : 0;
-      const int yd = y + 1 < h - 1 ? y + 1 : h - 1, yu = y - 1 > 0 ? y - 1 : 0;
-      const float fx = (float)x + 0.5f + (m.at(plane, y, xr) > m.at(plane, y, xl) ? 0.25f : -0.25f);
-      const float fy = (float)y + 0.5f + (m.at(plane, yd, x) > m.at(plane, yu, x) ? 0.25f : -0.25f);
-      out[0] = fx;
-      out[1] = fy;
-      out[2] = v;
-    }
-  }
+}
+
+static size_t refine_scratch(int P, int J, int D) {
+  return (size_t)P * J * sizeof(u64) + (size_t)P * D * sizeof(float) + 256;
+}
+
+template <class Map, class TagMap>
+static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, int h, int w, int D,
+                             const float* ans_in, float* ans_out, const int* person_img, int P, int do_adjust,
+                             int do_refine, float* scores, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  RTPE_REQUIRE(scratch && scratch_bytes >= refine_scratch(P, J, D), "adjust_refine: scratch too small");
+  u64* best_key = reinterpret_cast<u64*>(scratch);
+  float* mean_tag = reinterpret_cast<float*>(best_key + (size_t)P * J);
+  hipLaunchKernelGGL((adjust_prepare_kernel<Map>), dim3(P), dim3(64), 0, s, m, J, h, w, D, ans_in, ans_out,
+                     person_img, do_adjust, scores, mean_tag);
+  RTPE_HIP_CHECK(hipGetLastError());
+  if (!do_refine) return RTPE_OK;
+  RTPE_HIP_CHECK(hipMemsetAsync(best_key, 0, (size_t)P * J * sizeof(u64), s));
+  hipLaunchKernelGGL((refine_scan_kernel<Map, TagMap>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s, m, tm, J,
+                     h, w, D, ans_in, person_img, P, mean_tag, best_key);
+  RTPE_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL((refine_finalize_kernel<Map>), dim3((P * J + 255) / 256), dim3(256), 0, s, m, J, h, w, D,
+                     ans_in, ans_out, person_img, P, best_key);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -514,35 +620,37 @@ extern "C" int rtpe_topk_fused(const float* hm, int32_t hh, int32_t hw, int64_t 
                   reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int rtpe_adjust_refine(const float* det, const float* tag, int32_t J, int32_t h, int32_t w, int32_t D,
-                                  const float* ans_in, float* ans_out, const int32_t* person_img, int32_t P,
-                                  int32_t do_adjust, int32_t do_refine, float* scores, void* stream) {
-  RTPE_REQUIRE(det && tag && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && J > 0 && J <= kMaxJ &&
-                   D > 0 && D <= kMaxD,
+extern "C" int rtpe_adjust_refine_scratch_bytes(int32_t P, int32_t J, int32_t D, size_t* bytes) {
+  RTPE_REQUIRE(bytes && P >= 0 && J > 0 && D > 0, "adjust_refine_scratch_bytes: bad argument");
+  *bytes = refine_scratch(P, J, D);
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_adjust_refine(const float* det, const float* tag, int32_t N, int32_t J, int32_t h, int32_t w,
+                                  int32_t D, const float* ans_in, float* ans_out, const int32_t* person_img,
+                                  int32_t P, int32_t do_adjust, int32_t do_refine, float* scores, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
+  RTPE_REQUIRE(det && tag && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && N > 0 && J > 0 &&
+                   J <= kMaxJ && D > 0 && D <= kMaxD,
                "adjust_refine: bad argument (J<=%d, D<=%d)", kMaxJ, kMaxD);
   if (P <= 0) return RTPE_OK;
   DirectMap m{det, h, w};
   DirectTag tm{tag, h, w, D};
-  hipLaunchKernelGGL((adjust_refine_kernel<DirectMap, DirectTag>), dim3(P * J), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), m, tm, J, h, w, D, ans_in, ans_out, person_img,
-                     do_adjust, do_refine, scores);
-  RTPE_HIP_CHECK(hipGetLastError());
-  return RTPE_OK;
+  return adjust_refine_run(m, tm, N, J, h, w, D, ans_in, ans_out, person_img, P, do_adjust, do_refine, scores,
+                           scratch, scratch_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int rtpe_adjust_refine_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
-                                        const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride, int32_t J,
-                                        int32_t oh, int32_t ow, const float* ans_in, float* ans_out,
+                                        const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride, int32_t N,
+                                        int32_t J, int32_t oh, int32_t ow, const float* ans_in, float* ans_out,
                                         const int32_t* person_img, int32_t P, int32_t do_adjust,
-                                        int32_t do_refine, float* scores, void* stream) {
-  RTPE_REQUIRE(hm && tg && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && J > 0 && J <= kMaxJ,
+                                        int32_t do_refine, float* scores, void* scratch, size_t scratch_bytes,
+                                        void* stream) {
+  RTPE_REQUIRE(hm && tg && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && N > 0 && J > 0 && J <= kMaxJ,
                "adjust_refine_fused: bad argument");
   if (P <= 0) return RTPE_OK;
   BilinearMap m = make_bilinear(hm, hh, hw, hm_img_stride, J, oh, ow);
   BilinearTag tm{make_bilinear(tg, th, tw, tg_img_stride, J, oh, ow)};
-  hipLaunchKernelGGL((adjust_refine_kernel<BilinearMap, BilinearTag>), dim3(P * J), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), m, tm, J, oh, ow, 1, ans_in, ans_out, person_img,
-                     do_adjust, do_refine, scores);
-  RTPE_HIP_CHECK(hipGetLastError());
-  return RTPE_OK;
+  return adjust_refine_run(m, tm, N, J, oh, ow, 1, ans_in, ans_out, person_img, P, do_adjust, do_refine, scores,
+                           scratch, scratch_bytes, reinterpret_cast<hipStream_t>(stream));
 }

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "rtpe_hip.h"
@@ -181,16 +182,12 @@ struct Person {
 
 }  // namespace
 
-extern "C" int rtpe_match_by_tag(const float* tag_k, const int32_t* ind_k, const float* val_k, int32_t J,
-                                 int32_t K, int32_t D, int32_t w, int32_t max_num_people,
-                                 double detection_threshold, double tag_threshold, int32_t use_detection_val,
-                                 int32_t ignore_too_much, float* ans, int32_t max_people_out,
-                                 int32_t* n_people) {
-  if (!tag_k || !ind_k || !val_k || !n_people || J <= 0 || K <= 0 || D <= 0 || w <= 0 ||
-      (max_people_out > 0 && !ans)) {
-    rtpe::set_error("match_by_tag: bad argument");
-    return RTPE_E_INVALID;
-  }
+namespace {
+
+// one image; appends the people rows (J x (3+D) float32 each) to `out`
+void match_image(const float* tag_k, const int32_t* ind_k, const float* val_k, int32_t J, int32_t K, int32_t D,
+                 int32_t w, int32_t max_num_people, double detection_threshold, double tag_threshold,
+                 int32_t use_detection_val, int32_t ignore_too_much, std::vector<float>* out, int* n_found) {
   const int R = 3 + D;
   // numpy compares float64(val) with the Python float thresholds: keep them double
   const double det_thr = detection_threshold;
@@ -289,10 +286,70 @@ extern "C" int rtpe_match_by_tag(const float* tag_k, const int32_t* ind_k, const
       }
     }
   }
-  *n_people = (int)people.size();
-  const int n_out = std::min((int)people.size(), (int)max_people_out);
-  for (int p = 0; p < n_out; ++p)
-    for (int i = 0; i < J * R; ++i) ans[(size_t)p * J * R + i] = (float)people[p].rows[i];
+  *n_found = (int)people.size();
+  out->reserve(out->size() + people.size() * (size_t)J * R);
+  for (const Person& p : people)
+    for (int i = 0; i < J * R; ++i) out->push_back((float)p.rows[i]);
+}
+
+}  // namespace
+
+extern "C" int rtpe_match_by_tag(const float* tag_k, const int32_t* ind_k, const float* val_k, int32_t J,
+                                 int32_t K, int32_t D, int32_t w, int32_t max_num_people,
+                                 double detection_threshold, double tag_threshold, int32_t use_detection_val,
+                                 int32_t ignore_too_much, float* ans, int32_t max_people_out,
+                                 int32_t* n_people) {
+  if (!tag_k || !ind_k || !val_k || !n_people || J <= 0 || K <= 0 || D <= 0 || w <= 0 ||
+      (max_people_out > 0 && !ans)) {
+    rtpe::set_error("match_by_tag: bad argument");
+    return RTPE_E_INVALID;
+  }
+  std::vector<float> rows;
+  int n = 0;
+  match_image(tag_k, ind_k, val_k, J, K, D, w, max_num_people, detection_threshold, tag_threshold,
+              use_detection_val, ignore_too_much, &rows, &n);
+  *n_people = n;
+  const size_t keep = (size_t)std::min(n, (int)max_people_out) * J * (3 + D);
+  if (keep) memcpy(ans, rows.data(), keep * sizeof(float));
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_match_by_tag_batch(const float* tag_k, const int32_t* ind_k, const float* val_k, int32_t N,
+                                       int32_t J, int32_t K, int32_t D, int32_t w, int32_t max_num_people,
+                                       double detection_threshold, double tag_threshold,
+                                       int32_t use_detection_val, int32_t ignore_too_much, float* ans,
+                                       int32_t max_people_total, int32_t* person_img, int32_t* counts,
+                                       int32_t n_threads) {
+  if (!tag_k || !ind_k || !val_k || !counts || N <= 0 || J <= 0 || K <= 0 || D <= 0 || w <= 0 ||
+      (max_people_total > 0 && (!ans || !person_img))) {
+    rtpe::set_error("match_by_tag_batch: bad argument");
+    return RTPE_E_INVALID;
+  }
+  std::vector<std::vector<float>> rows(N);
+  std::vector<int> found(N, 0);
+  auto work = [&](int t, int nt) {
+    for (int n = t; n < N; n += nt)
+      match_image(tag_k + (size_t)n * J * K * D, ind_k + (size_t)n * J * K, val_k + (size_t)n * J * K, J, K, D, w,
+                  max_num_people, detection_threshold, tag_threshold, use_detection_val, ignore_too_much,
+                  &rows[n], &found[n]);
+  };
+  int nt = n_threads < 1 ? 1 : (n_threads > N ? N : n_threads);
+  if (nt == 1) {
+    work(0, 1);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t, nt);
+    for (auto& x : th) x.join();
+  }
+  const size_t R = (size_t)J * (3 + D);
+  size_t o = 0;
+  for (int n = 0; n < N; ++n) {
+    counts[n] = found[n];
+    for (int q = 0; q < found[n] && (int)o < max_people_total; ++q, ++o) {
+      memcpy(ans + o * R, rows[n].data() + (size_t)q * R, R * sizeof(float));
+      person_img[o] = n;
+    }
+  }
   return RTPE_OK;
 }
 

@@ -65,11 +65,17 @@ _SIGS = {
                                     c_int32, c_double, c_double, c_int32, c_int32, c_void_p, c_int32,
                                     POINTER(c_int32)]),
     "rtpe_munkres": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, POINTER(c_int32)]),
-    "rtpe_adjust_refine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
-                                     c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "rtpe_adjust_refine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    "rtpe_adjust_refine_scratch_bytes": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "rtpe_adjust_refine_fused": (c_int32, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_int32, c_int32,
-                                           c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                           c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+                                           c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
+    "rtpe_match_by_tag_batch": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, c_int32, c_double, c_double, c_int32, c_int32, c_void_p,
+                                          c_int32, c_void_p, c_void_p, c_int32]),
 }
 
 EXPORTS = tuple(_SIGS)
