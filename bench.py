@@ -137,6 +137,11 @@ def main():
     names = eng.program.names
     costs = [eng.op_cost(i, B, S, S) for i in range(n_ops)]
     by_name = {}
+    names = list(names)
+    for i in range(n_ops):
+        t = eng.op_tile(i, B, S, S)
+        ds = eng.program.tensors[eng.program.ops[i].out_t].ds_log2 if eng.program.ops[i].out_t >= 0 else 1
+        names[i] = "%s @/%d" % (names[i], 1 << ds) + (" [m%d n%d w%d %dx%d cc%d cb%d]" % tuple(t[:7]) if t[0] else "")
     for i, nm in enumerate(names):
         d = by_name.setdefault(nm, dict(n=0, ms=0.0, flops=0.0, bytes=0.0, res={}))
         d["n"] += 1
@@ -165,9 +170,9 @@ def main():
     if args.dump_ops:
         with open(args.dump_ops, "w") as f:
             f.write("# per-op-class HIP-event times, batch %d, %dx%d, avg over %d steps\n" % (B, S, S, args.steps))
-            f.write("%-34s %4s %9s %9s %9s %8s\n" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op"))
+            f.write("%-66s %4s %9s %9s %9s %8s\n" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op"))
             for nm, d in sorted(by_name.items(), key=lambda kv: -kv[1]["ms"]):
-                f.write("%-34s %4d %9.3f %9.1f %9.1f %8.1f\n" % (
+                f.write("%-66s %4d %9.3f %9.1f %9.1f %8.1f\n" % (
                     nm, d["n"], d["ms"], d["flops"] / max(d["ms"], 1e-9) / 1e9,
                     d["bytes"] / max(d["ms"], 1e-9) / 1e6, d["ms"] / d["n"] * 1e3))
             f.write("forward total (events) %.3f ms; wall %.3f ms\n" % (fwd_ms_events, fwd_s * 1e3))

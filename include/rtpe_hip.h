@@ -140,6 +140,10 @@ int rtpe_hrnet_forward_timed(rtpe_hrnet* h, const void* x, int32_t x_dtype,
 int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W,
                        double* flops, double* bytes);
 
+/* kernel variant of conv op i for (N,H,W): out8 = {cout tiles/wave, pixel
+ * tiles/wave, waves, tile_h, tile_w, channel chunk, cout blocks, LDS bytes} */
+int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8);
+
 /* ------------------------------------------------------------------------ *
  * Single layers (layer-level parity tests; same kernels the executor runs).
  * ------------------------------------------------------------------------ */

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(64) adjust_prepare_kernel(Map m, int J, int h,
 //     misses this joint is scored against every pixel of the stripe; the map is
 //     sampled once per pixel for all of them.  arg-max keys are merged with
 //     atomicMax (value bits << 32 | ~index: the first maximum wins, as np.argmax)
-template <class Map, class TagMap>
+template <class Map, class TagMap, bool kD1>
 __global__ void __launch_bounds__(256) refine_scan_kernel(Map m, TagMap tm, int J, int h, int w, int D,
                                                           const float* ans_in, const int* person_img, int P,
                                                           const float* mean_tag, u64* best_key) {
@@ -415,51 +415,81 @@ __global__ void __launch_bounds__(256) refine_scan_kernel(Map m, TagMap tm, int 
       for (int i = threadIdx.x; i < gn * D; i += 256)
         gmean[(i / D) * kMaxD + i % D] = mean_tag[(size_t)need[g0 + i / D] * D + i % D];
       __syncthreads();
-      u64 best[kRefineGroup];
+      // per-thread running arg-max: pixels are visited in increasing index order, so a
+      // strict '>' keeps the first maximum (np.argmax, group.py:233)
+      float bscore[kRefineGroup];
+      unsigned bidx[kRefineGroup];
 #pragma unroll
-      for (int q = 0; q < kRefineGroup; ++q) best[q] = 0;
-      for (int i = threadIdx.x; i < npix; i += 256) {
-        const int yy = i / w, x = i - yy * w, y = y_begin + yy;
-        const float dv = m.at(plane, y, x);
-        const unsigned nidx = 0xffffffffu - (unsigned)(y * w + x);
-        if (D == 1) {
+      for (int q = 0; q < kRefineGroup; ++q) { bscore[q] = -INFINITY; bidx[q] = 0xffffffffu; }
+      if (kD1) {
+        // D == 1 (what validate_hhrnet.py passes): branch-free over the 16 slots of the
+        // group; unused slots (>= gn) carry mean 0 and are dropped afterwards
+        float gm[kRefineGroup];
+#pragma unroll
+        for (int q = 0; q < kRefineGroup; ++q) gm[q] = q < gn ? gmean[q * kMaxD] : 0.f;
+        int y = y_begin + (int)(threadIdx.x / (unsigned)w), x = (int)(threadIdx.x % (unsigned)w);
+        const int dy = 256 / w, dx = 256 - dy * w;          // advance of 256 pixels in (y, x)
+        for (int i = threadIdx.x; i < npix; i += 256) {
+          const float dv = m.at(plane, y, x);
           const float tv = tm.at(plane, y, x, 0);
+          const unsigned idx = (unsigned)(y * w + x);
+          bool slow = false;
+          float kk[kRefineGroup];
 #pragma unroll
           for (int q = 0; q < kRefineGroup; ++q) {
-            if (q < gn) {
-              const float d0 = tv - gmean[q * kMaxD];
-              const float score = dv - rintf(sqrtf(d0 * d0));
-              const u64 key = ((u64)order_bits(score) << 32) | nidx;
-              best[q] = key > best[q] ? key : best[q];
+            const float a = fabsf(tv - gm[q]);
+            kk[q] = rintf(a);
+            // round(sqrt(fl(d*d))) == round(|d|) unless |d| sits within a few ulp of a
+            // half-integer (sqrt(fl(a*a)) is within 1.5*2^-24 relative of a)
+            slow |= fabsf(fabsf(a - kk[q]) - 0.5f) <= a * 4e-7f;
+          }
+          if (slow) {                                         // rare: the exact expression
+#pragma unroll
+            for (int q = 0; q < kRefineGroup; ++q) {
+              const float d0 = tv - gm[q];
+              kk[q] = rintf(sqrtf(d0 * d0));
             }
           }
-        } else {
-          float tv[kMaxD];
-          for (int d = 0; d < D; ++d) tv[d] = tm.at(plane, y, x, d);
 #pragma unroll
           for (int q = 0; q < kRefineGroup; ++q) {
-            if (q < gn) {
-              float ss;
-              if (D < 8) {
-                const float d0 = tv[0] - gmean[q * kMaxD];
-                ss = d0 * d0;
-                for (int d = 1; d < D; ++d) { const float dd = tv[d] - gmean[q * kMaxD + d]; ss = ss + dd * dd; }
-              } else {
-                float sq[kMaxD];
-                for (int d = 0; d < D; ++d) { const float dd = tv[d] - gmean[q * kMaxD + d]; sq[d] = dd * dd; }
-                ss = pairwise8_sum(sq, D);
-              }
-              const float score = dv - rintf(sqrtf(ss));
-              const u64 key = ((u64)order_bits(score) << 32) | nidx;
-              best[q] = key > best[q] ? key : best[q];
+            const float score = dv - kk[q];
+            const bool up = score > bscore[q] || bidx[q] == 0xffffffffu;
+            bscore[q] = up ? score : bscore[q];
+            bidx[q] = up ? idx : bidx[q];
+          }
+          x += dx; y += dy;
+          if (x >= w) { x -= w; y += 1; }
+        }
+      } else {
+        for (int i = threadIdx.x; i < npix; i += 256) {
+          const int yy = i / w, x = i - yy * w, y = y_begin + yy;
+          const float dv = m.at(plane, y, x);
+          const unsigned idx = (unsigned)(y * w + x);
+          float tv[kMaxD];
+          for (int d = 0; d < D; ++d) tv[d] = tm.at(plane, y, x, d);
+          for (int q = 0; q < gn; ++q) {
+            float ss;
+            if (D < 8) {
+              const float d0 = tv[0] - gmean[q * kMaxD];
+              ss = d0 * d0;
+              for (int d = 1; d < D; ++d) { const float dd = tv[d] - gmean[q * kMaxD + d]; ss = ss + dd * dd; }
+            } else {
+              float sq[kMaxD];
+              for (int d = 0; d < D; ++d) { const float dd = tv[d] - gmean[q * kMaxD + d]; sq[d] = dd * dd; }
+              ss = pairwise8_sum(sq, D);
             }
+            const float score = dv - rintf(sqrtf(ss));
+#pragma unroll
+            for (int u = 0; u < kRefineGroup; ++u)            // static register indexing
+              if (u == q && (score > bscore[u] || bidx[u] == 0xffffffffu)) { bscore[u] = score; bidx[u] = idx; }
           }
         }
       }
 #pragma unroll
       for (int q = 0; q < kRefineGroup; ++q) {
         if (q < gn) {
-          const u64 k = wave_max(best[q]);
+          const u64 mine = bidx[q] == 0xffffffffu ? 0 : make_key(bscore[q], bidx[q]);
+          const u64 k = wave_max(mine);
           if ((threadIdx.x & 63) == 0) atomicMax(&red[q], k);
         }
       }
@@ -512,8 +542,12 @@ static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, i
   RTPE_HIP_CHECK(hipGetLastError());
   if (!do_refine) return RTPE_OK;
   RTPE_HIP_CHECK(hipMemsetAsync(best_key, 0, (size_t)P * J * sizeof(u64), s));
-  hipLaunchKernelGGL((refine_scan_kernel<Map, TagMap>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s, m, tm, J,
-                     h, w, D, ans_in, person_img, P, mean_tag, best_key);
+  if (D == 1)
+    hipLaunchKernelGGL((refine_scan_kernel<Map, TagMap, true>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s,
+                       m, tm, J, h, w, D, ans_in, person_img, P, mean_tag, best_key);
+  else
+    hipLaunchKernelGGL((refine_scan_kernel<Map, TagMap, false>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s,
+                       m, tm, J, h, w, D, ans_in, person_img, P, mean_tag, best_key);
   RTPE_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL((refine_finalize_kernel<Map>), dim3((P * J + 255) / 256), dim3(256), 0, s, m, J, h, w, D,
                      ans_in, ans_out, person_img, P, best_key);

@@ -372,3 +372,20 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
   if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
   return RTPE_OK;
 }
+
+// introspection for bench / tuning: kernel variant and geometry of a conv op
+extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8) {
+  RTPE_REQUIRE(h && out8 && op >= 0 && op < (int)h->ops.size(), "op_tile: bad argument");
+  const OpState& o = h->ops[op];
+  memset(out8, 0, 8 * sizeof(int32_t));
+  if (o.n_geom == 0) return RTPE_OK;
+  const rtpe_op_desc& d = o.d;
+  const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+  const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
+  const bool dc = d.kind == RTPE_OP_DECONV;
+  const int Hp = dc ? Hi : Hi / d.stride, Wp = dc ? Wi : Wi / d.stride;
+  const ConvTile t = conv_make_tile(o.plan[0], N, Hp, Wp);
+  out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = (int32_t)t.lds_bytes;
+  return RTPE_OK;
+}
