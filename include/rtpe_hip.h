@@ -140,6 +140,16 @@ int rtpe_hrnet_forward_timed(rtpe_hrnet* h, const void* x, int32_t x_dtype,
 int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W,
                        double* flops, double* bytes);
 
+/* Per-shape plan autotuning (the reference runs with cudnn.benchmark = True,
+ * teacher_inference.py:31): runs one forward, then times every launch shape of
+ * every conv op on its real buffers and keeps the fastest for (N,H,W).  All
+ * shapes give bit-identical results.  Arguments as rtpe_hrnet_forward.
+ * Host-returning. */
+int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
+                        int32_t N, int32_t H, int32_t W,
+                        void* preds, void* refined, int32_t out_dtype,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* kernel variant of conv op i for (N,H,W): out8 = {cout tiles/wave, pixel
  * tiles/wave, waves, tile_h, tile_w, channel chunk, cout blocks, LDS bytes} */
 int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8);

@@ -22,6 +22,8 @@
 //     i.e. the NHWC store / residual load are 8-byte row pieces;
 //   * K order inside a channel chunk is flat [tap][channel], padded to 32, so
 //     Cin = 48 needs 14 MFMA k-steps for 9 taps instead of 18.
+#include <vector>
+
 #include "rtpe_common.h"
 
 namespace rtpe {
@@ -37,6 +39,19 @@ __device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }
 template <int MT, int NT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef RTPE_CONV_STAMPS
+#define RTPE_STAMP(i)                                   \
+  do {                                                  \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    stamp[i] = __builtin_readcyclecounter();            \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+  unsigned long long stamp[8];
+  unsigned long long seg_stage = 0, seg_k = 0;
+  RTPE_STAMP(0);
+#else
+#define RTPE_STAMP(i)
+#endif
   int* tapoff = reinterpret_cast<int*>(smem);
   char* tile = smem + kTapTableBytes;
 
@@ -99,24 +114,36 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   const _Float16* xin = a.x + (size_t)n * a.H_in * a.W_in * a.in_ld;
 
   int kf = 0;  // linear k-chunk index over (channel chunk, k chunk)
+  RTPE_STAMP(1);
   for (int cci = 0; cci < a.n_cchunks; ++cci) {
+    RTPE_STAMP(2);
     if (cci > 0) __syncthreads();
     // ---- stage the halo tile of channels [cci*cc, cci*cc+cc) ----
     const int cbase = cci * a.cc;
-#pragma unroll 4
-    for (int idx = tid; idx < total; idx += NTHREADS) {
-      const uint32_t hy = fdiv(idx, a.div_rowslots);
-      const uint32_t q = idx - hy * rowslots;
-      const uint32_t hx = fdiv(q, a.div_slots);
-      const uint32_t s = q - hx * slots;
-      const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in &&
-          cbase + (int)s * 8 < a.cin)
-        v = *reinterpret_cast<const uint4*>(xin + ((size_t)iy * a.W_in + ix) * a.in_ld + cbase + s * 8);
-      *reinterpret_cast<uint4*>(tile + (hy * a.halo_w + hx) * a.pstride + s * 16) = v;
+    // all loads of a batch are issued before the first LDS write: 8 x 16 B in flight per lane
+    for (int base = 0; base < total; base += NTHREADS * 8) {
+      uint4 v[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * NTHREADS + tid;
+        const uint32_t hy = fdiv(idx, a.div_rowslots);
+        const uint32_t q = idx - hy * rowslots;
+        const uint32_t hx = fdiv(q, a.div_slots);
+        const uint32_t s = q - hx * slots;
+        const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
+        dst[u] = idx < total ? (int)((hy * a.halo_w + hx) * a.pstride + s * 16) : -1;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (idx < total && (unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in &&
+            cbase + (int)s * 8 < a.cin)
+          v[u] = *reinterpret_cast<const uint4*>(xin + ((size_t)iy * a.W_in + ix) * a.in_ld + cbase + s * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<uint4*>(tile + dst[u]) = v[u];
     }
     __syncthreads();
+    RTPE_STAMP(3);
 
     // ---- k loop over [tap][channel] of this chunk ----
     for (int kci = 0; kci < a.kc; ++kci, ++kf) {
@@ -137,7 +164,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
       for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
     }
+    RTPE_STAMP(4);
+#ifdef RTPE_CONV_STAMPS
+    seg_stage += stamp[3] - stamp[2];
+    seg_k += stamp[4] - stamp[3];
+#endif
   }
+  RTPE_STAMP(5);
 
   // ---- epilogue: lane holds channels cbase4..cbase4+3 of pixel (nt, r) ----
   float4v al[MT], be[MT];
@@ -147,58 +180,97 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     al[m] = *reinterpret_cast<const float4v*>(a.alpha + c4);
     be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
   }
+  // The accumulator layout (4 channels of one pixel per lane) would make the NHWC
+  // store and the residual load 8-byte pieces scattered over 16 rows per
+  // instruction.  Instead each wave transposes its 16*NT pixels x 16*MT channels
+  // through its own slice of the (now free) input-tile LDS and then moves whole
+  // rows with 16-byte accesses: consecutive lanes cover consecutive bytes of a
+  // pixel row, consecutive pixels of a tile row are contiguous in NHWC.
+  constexpr int ROWB = MT * 32 + 16;      // LDS bytes per pixel row (+16: spreads the b64 writes over banks)
+  constexpr int CH = MT * 2;              // 16-byte chunks per pixel row
+  __syncthreads();                        // every wave is done reading the input tile
+  char* obuf = tile + wv * (NT * 16 * ROWB);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const uint32_t p = (wv * NT + nt) * 16 + r;
-    const uint32_t oyt = fdiv(p, a.div_tw);
-    const uint32_t oxt = p - oyt * a.tw;
-    const int py = py0 + (int)oyt, px = px0 + (int)oxt;
-    if (py >= a.H_pos || px >= a.W_pos) continue;
-    const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
-    const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int c4 = (cb * MT + m) * 16 + g * 4;
       float4v v = acc[m][nt];
+      half4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = v[j];
         if (a.round_conv) x = round16(x);
         x = round16(__builtin_fmaf(x, al[m][j], be[m][j]));
         v[j] = x;
+        o[j] = (_Float16)x;
       }
-      if (a.res != nullptr && c4 < a.cout_store) {
-        const half4 rr = *reinterpret_cast<const half4*>(a.res + pix * a.res_ld + c4);
+      *reinterpret_cast<half4*>(obuf + (nt * 16 + r) * ROWB + m * 32 + g * 8) = o;
+      if (a.y_nchw != nullptr) {          // heads: NCHW fp32/fp16 straight from the registers
+        const uint32_t p = (wv * NT + nt) * 16 + r;
+        const uint32_t oyt = fdiv(p, a.div_tw);
+        const uint32_t oxt = p - oyt * a.tw;
+        const int py = py0 + (int)oyt, px = px0 + (int)oxt;
+        if (py < a.H_pos && px < a.W_pos) {
+          const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+          const int c4 = (cb * MT + m) * 16 + g * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = round16(v[j] + (float)rr[j]);
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-      }
-      if (a.y != nullptr && c4 < a.cout_store) {
-        half4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
-        *reinterpret_cast<half4*>(a.y + pix * a.out_ld + c4) = o;
-      }
-      if (a.y_nchw != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = c4 + j;
-          if (c < a.nchw_channels) {
-            const size_t o = (((size_t)n * a.nchw_channels + c) * a.H_full + oy) * a.W_full + ox;
-            if (a.nchw_f32)
-              reinterpret_cast<float*>(a.y_nchw)[o] = v[j];
-            else
-              reinterpret_cast<_Float16*>(a.y_nchw)[o] = (_Float16)v[j];
+          for (int j = 0; j < 4; ++j) {
+            const int c = c4 + j;
+            if (c < a.nchw_channels) {
+              const float x = a.relu ? (v[j] > 0.f ? v[j] : 0.f) : v[j];
+              const size_t oi = (((size_t)n * a.nchw_channels + c) * a.H_full + oy) * a.W_full + ox;
+              if (a.nchw_f32)
+                reinterpret_cast<float*>(a.y_nchw)[oi] = x;
+              else
+                reinterpret_cast<_Float16*>(a.y_nchw)[oi] = (_Float16)x;
+            }
           }
         }
       }
     }
   }
+  if (a.y != nullptr) {
+    const int cblk = cb * MT * 16;
+#pragma unroll
+    for (int it = 0; it < (NT * 16 * CH + 63) / 64; ++it) {
+      const int c = it * 64 + lane;                 // chunk index inside this wave's pixels
+      if (c >= NT * 16 * CH) continue;
+      const int pw = c / CH, slot = c - pw * CH;    // pixel of the wave, 16-byte slot of its row
+      const uint32_t p = wv * NT * 16 + pw;
+      const uint32_t oyt = fdiv(p, a.div_tw);
+      const uint32_t oxt = p - oyt * a.tw;
+      const int py = py0 + (int)oyt, px = px0 + (int)oxt;
+      const int ch = cblk + slot * 8;
+      if (py >= a.H_pos || px >= a.W_pos || ch >= a.cout_store) continue;
+      const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+      const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
+      half8 v = *reinterpret_cast<const half8*>(obuf + pw * ROWB + slot * 16);
+      if (a.res != nullptr) {
+        const half8 rr = *reinterpret_cast<const half8*>(a.res + pix * a.res_ld + ch);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0.f ? v[j] : (_Float16)0.f;
+      }
+      *reinterpret_cast<half8*>(a.y + pix * a.out_ld + ch) = v;
+    }
+  }
+#ifdef RTPE_CONV_STAMPS
+  RTPE_STAMP(6);
+  if (a.dbg != nullptr && lane == 0) {
+    atomicAdd(&a.dbg[0], stamp[1] - stamp[0]);   // setup (tap table, pixel bases, first weights)
+    atomicAdd(&a.dbg[1], seg_stage);             // staging incl. barriers
+    atomicAdd(&a.dbg[2], seg_k);                 // k loops
+    atomicAdd(&a.dbg[3], stamp[6] - stamp[5]);   // epilogue
+    atomicAdd(&a.dbg[4], stamp[6] - stamp[0]);   // whole wave
+    atomicAdd(&a.dbg[5], 1ull);
+  }
+#endif
 }
 
+// (diagnostic stamp flush is emitted at the end of the kernel body above)
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
@@ -279,21 +351,81 @@ static const TileCand kCands[] = {
     {4, 5, 16, 20}, {4, 5, 20, 16}, {4, 5, 8, 40},  {4, 5, 40, 8},
 };
 
-static size_t tile_lds(const ConvPlan& p, int th, int tw) {
+static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
   const int hh = (th - 1) * p.in_mul + p.tapw, hw = (tw - 1) * p.in_mul + p.tapw;
-  return (size_t)kTapTableBytes + (size_t)hh * hw * p.pstride;
+  const size_t in_tile = (size_t)hh * hw * p.pstride;
+  const size_t out_tile = (size_t)waves * nt * 16 * (p.mt * 32 + 16);   // epilogue transpose buffer
+  return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
+}
+
+// persistent kernel (conv_persist.hip): two LDS tile buffers + a loader wave
+static ConvTile make_persist_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+  static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
+  static const int force_waves = getenv("RTPE_CONV_WAVES") ? atoi(getenv("RTPE_CONV_WAVES")) : 0;
+  static const int force_wgs = getenv("RTPE_CONV_WGS_PER_CU") ? atoi(getenv("RTPE_CONV_WGS_PER_CU")) : 0;
+  double best_score = 1e30;
+  ConvTile best;
+  memset(&best, 0, sizeof(best));
+  for (const TileCand& c : kCands) {
+    if (p.mt == 4 && c.nt == 8) continue;
+    if (c.nt == 8 && !force_nt) continue;            // residual prefetch + 96 accumulators would not fit 2 waves/SIMD
+    if (force_nt && c.nt != force_nt) continue;
+    if (force_waves && c.waves != force_waves) continue;
+    const int hh = (c.th - 1) * p.in_mul + p.tapw, hw = (c.tw - 1) * p.in_mul + p.tapw;
+    size_t in_tile = (size_t)hh * hw * p.pstride;
+    const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
+    size_t buf = in_tile > out_tile ? in_tile : out_tile;
+    buf = (buf + 1023) / 1024 * 1024;
+    const size_t lds = kTapTableBytes + 2 * buf;
+    if (lds > 160 * 1024) continue;
+    int wgs_cu = (int)(160 * 1024 / lds);
+    const int by_waves = 12 / (c.waves + 1);         // <= 168 VGPRs -> 3 waves per SIMD = 12 per CU
+    if (wgs_cu > by_waves) wgs_cu = by_waves;
+    if (wgs_cu > 3) wgs_cu = 3;
+    if (force_wgs && wgs_cu > force_wgs) wgs_cu = force_wgs;
+    const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
+    const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
+                         ((double)H_pos * W_pos);
+    const long units = tiles * p.n_cb;
+    // workgroups: a multiple of 8 (XCDs), per-XCD count a multiple of n_cb
+    long G = 256L * wgs_cu / 8;
+    const long need = (units + 7) / 8;
+    if (G > need) G = need;
+    G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
+    const double rounds = (double)units / (8.0 * G);  // units per workgroup
+    const double imbalance = (double)((long)(rounds + 0.999)) / rounds;
+    double score = waste * imbalance;
+    const double conc_waves = (double)(8 * G) * c.waves / 256.0;   // MFMA waves per CU
+    if (conc_waves < 8) score *= 1.0 + 0.05 * (8 - conc_waves);
+    score *= 1.0 + 0.15 / c.nt;
+    const double halo = (double)hh * hw / ((double)c.th * c.tw * p.in_mul * p.in_mul);
+    score *= 1.0 + 0.15 * (halo - 1.0);
+    if (score < best_score) {
+      best_score = score;
+      best.nt = c.nt; best.waves = c.waves; best.th = c.th; best.tw = c.tw;
+      best.lds_bytes = lds; best.kind = 1; best.grid = (int)(8 * G); best.buf_bytes = (int)buf;
+    }
+  }
+  return best;
 }
 
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+  static const int persist = getenv("RTPE_CONV_PERSIST") ? atoi(getenv("RTPE_CONV_PERSIST")) : 1;
+  if (persist && p.cc == 48 && p.pstride == 96) {
+    ConvTile t = make_persist_tile(p, N, H_pos, W_pos);
+    if (t.nt) return t;
+  }
   static const long lds_cap = getenv("RTPE_CONV_LDS_CAP") ? atol(getenv("RTPE_CONV_LDS_CAP")) : 80 * 1024;
   static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
+  static const int force_waves = getenv("RTPE_CONV_WAVES") ? atoi(getenv("RTPE_CONV_WAVES")) : 0;
   double best_score = 1e30;
   ConvTile best;
   memset(&best, 0, sizeof(best));
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;  // 128 accumulators + operands: keep 2 waves/SIMD
-    if (force_nt && c.nt != force_nt && !(c.nt == 5)) continue;
-    const size_t lds = tile_lds(p, c.th, c.tw);
+    if (force_nt && c.nt != force_nt) continue;
+    if (force_waves && c.waves != force_waves) continue;
+    const size_t lds = tile_lds(p, c.th, c.tw, c.waves, c.nt);
     if ((long)lds > lds_cap && !(c.nt == 2)) continue;
     const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw);
     const double waste = (double)tiles * c.th * c.tw / ((double)H_pos * W_pos);
@@ -331,6 +463,11 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->div_cc = make_fastdiv(p.cc);
   a->div_tiles_x = make_fastdiv(a->tiles_x);
   a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
+  a->n_cb = p.n_cb;
+  a->buf_bytes = t.buf_bytes;
+  // ablation for profiling only: RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
+  static const int skipk = getenv("RTPE_CONV_SKIPK") ? atoi(getenv("RTPE_CONV_SKIPK")) : 0;
+  if (skipk) a->kc = 0;
 }
 
 template <int MT, int NT, int WAVES>
@@ -348,12 +485,61 @@ static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStr
   return RTPE_OK;
 }
 
+// every launch shape worth timing for a layer (the autotuner picks the fastest; all of
+// them give bit-identical results because the k order does not depend on the tiling)
+void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector<ConvTile>* out) {
+  out->clear();
+  double min_waste = 1e30;
+  for (const TileCand& c : kCands) {
+    const double w = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
+                     ((double)H_pos * W_pos);
+    if (w < min_waste) min_waste = w;
+  }
+  for (const TileCand& c : kCands) {
+    if (p.mt == 4 && c.nt == 8) continue;
+    const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
+                         ((double)H_pos * W_pos);
+    if (waste > 1.35 * min_waste) continue;
+    const int hh = (c.th - 1) * p.in_mul + p.tapw, hw = (c.tw - 1) * p.in_mul + p.tapw;
+    const size_t in_tile = (size_t)hh * hw * p.pstride;
+    const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
+    ConvTile t;
+    memset(&t, 0, sizeof(t));
+    t.nt = c.nt; t.waves = c.waves; t.th = c.th; t.tw = c.tw;
+    t.lds_bytes = tile_lds(p, c.th, c.tw, c.waves, c.nt);
+    if (t.lds_bytes <= 160 * 1024) out->push_back(t);              // one workgroup per tile
+    if (p.cc == 48 && p.pstride == 96 && c.nt <= 5) {              // persistent + loader wave
+      size_t buf = in_tile > out_tile ? in_tile : out_tile;
+      buf = (buf + 1023) / 1024 * 1024;
+      const size_t lds = kTapTableBytes + 2 * buf;
+      if (lds > 160 * 1024) continue;
+      int max_wgs = (int)(160 * 1024 / lds);
+      if (max_wgs > 12 / (c.waves + 1)) max_wgs = 12 / (c.waves + 1);
+      const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
+      const long units = tiles * p.n_cb;
+      for (int wgs = 1; wgs <= max_wgs; ++wgs) {
+        long G = 256L * wgs / 8;
+        const long need = (units + 7) / 8;
+        if (G > need) G = need;
+        G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
+        ConvTile q = t;
+        q.kind = 1; q.lds_bytes = lds; q.grid = (int)(8 * G); q.buf_bytes = (int)buf;
+        out->push_back(q);
+      }
+    }
+  }
+}
+
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
   RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves, "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
   RTPE_REQUIRE(a.kc * 4 * sizeof(int) <= (size_t)kTapTableBytes, "k chunk table overflow (kc=%d)", a.kc);
-  RTPE_REQUIRE(a.in_ld % 8 == 0 && (a.y == nullptr || a.out_ld % 4 == 0), "conv: in_ld %% 8 / out_ld %% 4");
+  RTPE_REQUIRE(a.in_ld % 8 == 0 && (a.y == nullptr || (a.out_ld % 8 == 0 && a.cout_store % 8 == 0 &&
+                                                       ((uintptr_t)a.y & 15) == 0)),
+               "conv: NHWC views must be 16-byte aligned with channel counts that are multiples of 8");
+  RTPE_REQUIRE(a.res == nullptr || (a.res_ld % 8 == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
+  if (t.kind == 1) return conv_persist_launch(p, t, a, s);
 #define RTPE_V(MTv, NTv, Wv) \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_variant<MTv, NTv, Wv>(t, a, p.n_cb, s);
   RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5)

@@ -3,6 +3,8 @@
 // kernels of conv_mfma.hip / elementwise.hip.  Owns only the packed weights.
 #include <stdarg.h>
 
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "rtpe_common.h"
@@ -41,6 +43,8 @@ using namespace rtpe;
 struct rtpe_hrnet {
   int device;
   std::vector<OpState> ops;
+  // autotuned launch shapes: (N, H, W) -> one ConvTile per (op, parity class); nt == 0 = not tuned
+  std::map<std::tuple<int, int, int>, std::vector<ConvTile>> tuned;
   std::vector<rtpe_tensor_desc> tensors;
   int n_slots;
   char* arena;        // device: packed weights + affine params
@@ -179,7 +183,8 @@ extern "C" int rtpe_hrnet_workspace_bytes(const rtpe_hrnet* h, int32_t N, int32_
 }
 
 static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
-               int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms) {
+               int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms,
+               int only_op = -1, int only_k = -1, const ConvTile* force = nullptr) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
   RTPE_REQUIRE(N > 0 && H % 32 == 0 && W % 32 == 0 && H >= 32 && W >= 32, "forward: N=%d H=%d W=%d", N, H, W);
   RTPE_REQUIRE(x_dtype == RTPE_DTYPE_F16 || x_dtype == RTPE_DTYPE_F32, "forward: x dtype");
@@ -201,7 +206,13 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     for (auto& e : ev) RTPE_HIP_CHECK(hipEventCreate(&e));
     RTPE_HIP_CHECK(hipEventRecord(ev[0], s));
   }
+  const std::vector<ConvTile>* tuned = nullptr;
+  {
+    auto it = h->tuned.find(std::make_tuple(N, H, W));
+    if (it != h->tuned.end()) tuned = &it->second;
+  }
   for (size_t i = 0; i < h->ops.size(); ++i) {
+    if (only_op >= 0 && (int)i != only_op) continue;
     const OpState& o = h->ops[i];
     const rtpe_op_desc& d = o.d;
     int rc = RTPE_OK;
@@ -221,10 +232,12 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       const bool dc = d.kind == RTPE_OP_DECONV;
       const int Ho = dc ? Hi * 2 : Hi / d.stride, Wo = dc ? Wi * 2 : Wi / d.stride;
       for (int k = 0; k < o.n_geom && rc == RTPE_OK; ++k) {
+        if (only_k >= 0 && k != only_k) continue;
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         a.x = tptr(d.in_t, d.in_coff);
         a.in_ld = ti.channels;
+        a.x_bytes = (size_t)N * Hi * Wi * ti.channels * 2 - (size_t)d.in_coff * 2;
         a.w = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[k]);
         a.alpha = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
         a.beta = a.alpha + o.plan[0].cout_pad;
@@ -254,7 +267,13 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         }
         a.relu = (d.flags & RTPE_F_RELU) ? 1 : 0;
         a.round_conv = (d.flags & RTPE_F_ROUND_CONV) ? 1 : 0;
-        const ConvTile tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos);
+        ConvTile tile;
+        if (force)
+          tile = *force;
+        else if (tuned && (*tuned)[i * 4 + k].nt)
+          tile = (*tuned)[i * 4 + k];
+        else
+          tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
         rc = conv_launch(o.plan[k], tile, a, s);
       }
@@ -336,7 +355,7 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
                                 int32_t cout, int32_t ksize, int32_t stride, int32_t flags, const void* res,
                                 void* y, void* stream) {
   RTPE_REQUIRE(x && w_host && alpha_host && beta_host && y, "conv2d_nhwc: null argument");
-  RTPE_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin % 8 == 0 && cout % 4 == 0,
+  RTPE_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin % 8 == 0 && cout % 8 == 0,
                "conv2d_nhwc: k=%d s=%d cin=%d cout=%d unsupported", ksize, stride, cin, cout);
   RTPE_REQUIRE(H % stride == 0 && W % stride == 0, "conv2d_nhwc: H, W must be multiples of the stride");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -355,6 +374,7 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.x = reinterpret_cast<const _Float16*>(x); a.in_ld = cin;
+  a.x_bytes = (size_t)N * H * W * cin * 2;
   a.w = reinterpret_cast<const _Float16*>(dev);
   a.alpha = reinterpret_cast<const float*>(dev + wb); a.beta = a.alpha + p.cout_pad;
   a.res = reinterpret_cast<const _Float16*>(res); a.res_ld = cout;
@@ -365,8 +385,25 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
   a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
   const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos);
   conv_fill_args(g, p, tile, &a);
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long* dbg = nullptr;
+  hipMalloc(reinterpret_cast<void**>(&dbg), 128);
+  hipMemset(dbg, 0, 128);
+  a.dbg = dbg;
+#endif
   int rc = conv_launch(p, tile, a, s);
   hipError_t es = hipStreamSynchronize(s);
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long hd[16];
+  hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost);
+  hipFree(dbg);
+  if (hd[5])
+    fprintf(stderr, "conv stamps (kind %d): n %llu | per wave(-unit) cycles: setup %llu stage/wait1 %llu kloop %llu epilogue %llu total/wait2 %llu\n",
+            tile.kind, hd[5], hd[0] / hd[5], hd[1] / hd[5], hd[2] / hd[5], hd[3] / hd[5], hd[4] / hd[5]);
+  if (hd[10])
+    fprintf(stderr, "   loader per stage: vmcnt-wait %llu barrier1 %llu issue %llu barriersE+2 %llu (stages %llu)\n",
+            hd[6] / hd[10], hd[7] / hd[10], hd[8] / hd[10], hd[9] / hd[10], hd[10]);
+#endif
   hipFree(dev);
   if (rc != RTPE_OK) return rc;
   if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
@@ -384,8 +421,93 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
   const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
   const bool dc = d.kind == RTPE_OP_DECONV;
   const int Hp = dc ? Hi : Hi / d.stride, Wp = dc ? Wi : Wi / d.stride;
-  const ConvTile t = conv_make_tile(o.plan[0], N, Hp, Wp);
+  ConvTile t = conv_make_tile(o.plan[0], N, Hp, Wp);
+  {
+    auto it = h->tuned.find(std::make_tuple(N, H, W));
+    if (it != h->tuned.end() && it->second[op * 4].nt) t = it->second[op * 4];
+  }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = (int32_t)t.lds_bytes;
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind ? -t.grid : (int32_t)t.lds_bytes;
+  return RTPE_OK;
+}
+
+// Per-shape plan autotuning (the reference runs its GPU path with cudnn.benchmark = True,
+// teacher_inference.py:31).  Layers that look alike form a class; in round r every class
+// runs its r-th launch shape (conv_enum_tiles) inside complete, per-op-timed forward
+// passes, so each shape is measured in the cache state it will really see; the shape with
+// the smallest summed time wins for the class.  All shapes give bit-identical results.
+// Host-returning.
+extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H, int32_t W,
+                                   void* preds, void* refined, int32_t out_dtype, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  RTPE_REQUIRE(h != nullptr, "autotune: null handle");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const auto shape = std::make_tuple(N, H, W);
+  h->tuned.erase(shape);
+  const size_t n_ops = h->ops.size();
+  std::vector<float> ms(n_ops);
+  int rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
+  if (rc != RTPE_OK) return rc;
+
+  typedef std::tuple<int, int, int, int, int, int, int, int> Key;
+  struct Class { std::vector<size_t> ops; std::vector<std::vector<ConvTile>> cands; std::vector<double> t; };
+  std::map<Key, Class> classes;
+  for (size_t i = 0; i < n_ops; ++i) {
+    const OpState& o = h->ops[i];
+    const rtpe_op_desc& d = o.d;
+    if (o.n_geom == 0) continue;
+    const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+    const Key key = std::make_tuple(d.cin, d.cout, d.ksize, d.stride, (int)d.kind, (int)ti.ds_log2, d.res_t >= 0 ? 1 : 0,
+                                    (int)(d.flags & (RTPE_F_OUT_PREDS | RTPE_F_OUT_REFINED | RTPE_F_NO_NHWC)));
+    Class& c = classes[key];
+    if (c.ops.empty()) {
+      const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
+      const bool dc = d.kind == RTPE_OP_DECONV;
+      const int Hp = dc ? Hi : Hi / d.stride, Wp = dc ? Wi : Wi / d.stride;
+      c.cands.resize(o.n_geom);
+      for (int k = 0; k < o.n_geom; ++k) conv_enum_tiles(o.plan[k], N, Hp, Wp, &c.cands[k]);
+      size_t nc = c.cands[0].size();
+      for (int k = 1; k < o.n_geom; ++k) nc = c.cands[k].size() < nc ? c.cands[k].size() : nc;
+      c.t.assign(nc, 0.0);
+    }
+    c.ops.push_back(i);
+  }
+  size_t rounds = 0;
+  for (auto& kv : classes) rounds = kv.second.t.size() > rounds ? kv.second.t.size() : rounds;
+  std::vector<ConvTile> trial(n_ops * 4);
+  for (size_t r = 0; r < rounds; ++r) {
+    for (auto& b : trial) memset(&b, 0, sizeof(b));
+    for (auto& kv : classes) {
+      Class& c = kv.second;
+      if (c.t.empty()) continue;
+      const size_t ci = r < c.t.size() ? r : c.t.size() - 1;
+      for (size_t i : c.ops)
+        for (size_t k = 0; k < c.cands.size(); ++k) trial[i * 4 + k] = c.cands[k][ci];
+    }
+    h->tuned[shape] = trial;
+    std::vector<float> best_ms(n_ops, 1e30f);
+    for (int rep = 0; rep < 3; ++rep) {           // first repetition also warms caches for this choice
+      rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
+      if (rc != RTPE_OK) { h->tuned.erase(shape); return rc; }
+      if (rep == 0) continue;
+      for (size_t i = 0; i < n_ops; ++i) best_ms[i] = ms[i] < best_ms[i] ? ms[i] : best_ms[i];
+    }
+    for (auto& kv : classes) {
+      Class& c = kv.second;
+      if (r < c.t.size())
+        for (size_t i : c.ops) c.t[r] += best_ms[i];
+    }
+  }
+  std::vector<ConvTile> best(n_ops * 4);
+  for (auto& b : best) memset(&b, 0, sizeof(b));
+  for (auto& kv : classes) {
+    Class& c = kv.second;
+    if (c.t.empty()) continue;
+    size_t bi = 0;
+    for (size_t j = 1; j < c.t.size(); ++j) if (c.t[j] < c.t[bi]) bi = j;
+    for (size_t i : c.ops)
+      for (size_t k = 0; k < c.cands.size(); ++k) best[i * 4 + k] = c.cands[k][bi];
+  }
+  h->tuned[shape] = best;
   return RTPE_OK;
 }

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "rtpe_hip.h"
 
@@ -73,6 +74,10 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int relu, round_conv;
   FastDiv div_tw, div_slots, div_rowslots, div_cc, div_tiles_x, div_tiles_xy;
+  size_t x_bytes;        // bytes from x to the end of its tensor (buffer bounds of the LDS-DMA path)
+  int n_cb;              // cout blocks
+  int buf_bytes;         // persistent kernel: bytes of one LDS tile buffer
+  unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
 
 struct ConvPlan {       // weight-layout half of the plan (fixed at create time)
@@ -84,9 +89,12 @@ struct ConvPlan {       // weight-layout half of the plan (fixed at create time)
 };
 
 struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
-  int nt, waves;        // pixel tiles (x16) per wave, waves per workgroup
+  int nt, waves;        // pixel tiles (x16) per wave, MFMA waves per workgroup
   int th, tw;
   size_t lds_bytes;
+  int kind;             // 0: one workgroup per tile (conv_mfma.hip), 1: persistent + loader wave (conv_persist.hip)
+  int grid;             // persistent: number of workgroups
+  int buf_bytes;        // persistent: one LDS tile buffer
 };
 
 struct ConvGeom {       // logical layer, independent of the batch
@@ -97,12 +105,14 @@ struct ConvGeom {       // logical layer, independent of the batch
 ConvPlan conv_make_plan(const ConvGeom& g);
 // choose the tile for a position grid (N images of H_pos x W_pos positions)
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos);
+void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector<ConvTile>* out);
 // pack fp16 weights (host) into fragment order; w is OIHW (IOHW 4x4 for deconv classes)
 void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const uint16_t* w,
                        uint16_t* packed);
 // fill geometry / divisors of `a` (pointers, sizes and flags are the caller's)
 void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, ConvArgs* a);
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+int conv_persist_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 
 // ---- elementwise / stem (elementwise.hip) ---------------------------------
 struct FuseArgs {
