@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--weights", default="W0", choices=["W0", "W1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=1)
     ap.add_argument("--dump-ops", default="", help="write the per-op table to this file")
     return ap.parse_args()
 
@@ -192,11 +192,16 @@ def main():
         net(xc[:1])                                          # warm-up
         c0 = time.perf_counter()
         n_done = 0
+        t_fwd = t_dec = 0.0
         for i in range(args.cpu_images):
+            a0 = time.perf_counter()
             p, r = net(xc[i:i + 1])
+            a1 = time.perf_counter()
             hms = decode_ref.upsample_bilinear(r, S, S)
             aes = decode_ref.upsample_bilinear(p[:, 17:], S, S)
             decode_ref.HeatmapParserRef().parse(hms, aes.unsqueeze(-1))
+            t_fwd += a1 - a0
+            t_dec += time.perf_counter() - a1
             n_done += 1
             print("cpu baseline: image %d done at %.1f s" % (n_done, time.perf_counter() - c0), file=sys.stderr,
                   flush=True)
@@ -205,7 +210,8 @@ def main():
         cdt = time.perf_counter() - c0
         cpu = {"value": round(n_done / cdt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
                "sample": "%d image(s) of the same synthetic batch, forward (half wrapper) + bilinear + parse, "
-                         "oracle/ on torch CPU with %d threads" % (n_done, cores)}
+                         "oracle/ on torch CPU with %d threads; forward %.1f s + decode %.1f s per image"
+                         % (n_done, cores, t_fwd / max(n_done, 1), t_dec / max(n_done, 1))}
 
     value = world * B * args.steps / dt
     out = {
