@@ -135,6 +135,15 @@ int rtpe_hrnet_forward_timed(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                              void* workspace, size_t workspace_bytes, void* stream,
                              float* op_ms, int32_t n_ops);
 
+/* rtpe_hrnet_forward that also records one HIP event per op into `slot`
+ * (0..63) WITHOUT synchronising; rtpe_hrnet_read_record() later waits for
+ * those events and returns the per-op times in ms (host-returning). */
+int rtpe_hrnet_forward_record(rtpe_hrnet* h, const void* x, int32_t x_dtype,
+                              int32_t N, int32_t H, int32_t W,
+                              void* preds, void* refined, int32_t out_dtype,
+                              void* workspace, size_t workspace_bytes, void* stream, int32_t slot);
+int rtpe_hrnet_read_record(rtpe_hrnet* h, int32_t slot, float* op_ms, int32_t n_ops);
+
 /* algorithmic cost of op i for (N,H,W): flops and HBM bytes of a layer-fused
  * execution (SURVEY.md section 8d accounting). */
 int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W,

@@ -45,6 +45,7 @@ struct rtpe_hrnet {
   std::vector<OpState> ops;
   // autotuned launch shapes: (N, H, W) -> one ConvTile per (op, parity class); nt == 0 = not tuned
   std::map<std::tuple<int, int, int>, std::vector<ConvTile>> tuned;
+  std::map<int, std::vector<hipEvent_t>> records;   // per-op events of rtpe_hrnet_forward_record, by slot
   std::vector<rtpe_tensor_desc> tensors;
   int n_slots;
   char* arena;        // device: packed weights + affine params
@@ -157,6 +158,8 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
 
 extern "C" int rtpe_hrnet_destroy(rtpe_hrnet* h) {
   if (!h) return RTPE_OK;
+  for (auto& kv : h->records)
+    for (auto& e : kv.second) hipEventDestroy(e);
   if (h->arena) hipFree(h->arena);
   delete h;
   return RTPE_OK;
@@ -184,7 +187,8 @@ extern "C" int rtpe_hrnet_workspace_bytes(const rtpe_hrnet* h, int32_t N, int32_
 
 static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
                int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms,
-               int only_op = -1, int only_k = -1, const ConvTile* force = nullptr) {
+               int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
+               std::vector<hipEvent_t>* rec = nullptr) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
   RTPE_REQUIRE(N > 0 && H % 32 == 0 && W % 32 == 0 && H >= 32 && W >= 32, "forward: N=%d H=%d W=%d", N, H, W);
   RTPE_REQUIRE(x_dtype == RTPE_DTYPE_F16 || x_dtype == RTPE_DTYPE_F32, "forward: x dtype");
@@ -205,6 +209,14 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     ev.resize(h->ops.size() + 1);
     for (auto& e : ev) RTPE_HIP_CHECK(hipEventCreate(&e));
     RTPE_HIP_CHECK(hipEventRecord(ev[0], s));
+  }
+  if (rec) {                         // non-blocking recording into caller-kept events
+    if (rec->size() != h->ops.size() + 1) {
+      for (auto& e : *rec) hipEventDestroy(e);
+      rec->resize(h->ops.size() + 1);
+      for (auto& e : *rec) RTPE_HIP_CHECK(hipEventCreate(&e));
+    }
+    RTPE_HIP_CHECK(hipEventRecord((*rec)[0], s));
   }
   const std::vector<ConvTile>* tuned = nullptr;
   {
@@ -294,6 +306,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     }
     if (rc != RTPE_OK) return rc;
     if (timed) RTPE_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+    if (rec) RTPE_HIP_CHECK(hipEventRecord((*rec)[i + 1], s));
   }
   if (timed) {
     RTPE_HIP_CHECK(hipEventSynchronize(ev.back()));
@@ -509,5 +522,27 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
       for (size_t k = 0; k < c.cands.size(); ++k) best[i * 4 + k] = c.cands[k][bi];
   }
   h->tuned[shape] = best;
+  return RTPE_OK;
+}
+
+// rtpe_hrnet_forward that also records one HIP event per op into `slot` WITHOUT
+// synchronising; rtpe_hrnet_read_record(slot) later waits for them and returns the
+// per-op times.  Lets bench.py time the ops inside a pipelined timed region.
+extern "C" int rtpe_hrnet_forward_record(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H,
+                                         int32_t W, void* preds, void* refined, int32_t out_dtype,
+                                         void* workspace, size_t workspace_bytes, void* stream, int32_t slot) {
+  RTPE_REQUIRE(h != nullptr && slot >= 0 && slot < 64, "forward_record: bad slot");
+  return run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes,
+             reinterpret_cast<hipStream_t>(stream), nullptr, 0, -1, -1, nullptr, &h->records[slot]);
+}
+
+extern "C" int rtpe_hrnet_read_record(rtpe_hrnet* h, int32_t slot, float* op_ms, int32_t n_ops) {
+  RTPE_REQUIRE(h != nullptr && op_ms != nullptr, "read_record: null argument");
+  auto it = h->records.find(slot);
+  RTPE_REQUIRE(it != h->records.end() && it->second.size() == h->ops.size() + 1 && n_ops >= (int)h->ops.size(),
+               "read_record: nothing recorded in slot %d", slot);
+  RTPE_HIP_CHECK(hipEventSynchronize(it->second.back()));
+  for (size_t i = 0; i < h->ops.size(); ++i)
+    RTPE_HIP_CHECK(hipEventElapsedTime(&op_ms[i], it->second[i], it->second[i + 1]));
   return RTPE_OK;
 }

@@ -46,6 +46,9 @@ _SIGS = {
     "rtpe_hrnet_forward_timed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                            c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p,
                                            POINTER(c_float), c_int32]),
+    "rtpe_hrnet_forward_record": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                            c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p, c_int32]),
+    "rtpe_hrnet_read_record": (c_int32, [c_void_p, c_int32, POINTER(c_float), c_int32]),
     "rtpe_hrnet_op_cost": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      POINTER(c_double), POINTER(c_double)]),
     "rtpe_hrnet_autotune": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,

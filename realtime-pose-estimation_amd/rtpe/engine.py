@@ -104,6 +104,34 @@ class TeacherPipeline:
         hw = tuple(out_hw) if out_hw is not None else tuple(images.shape[2:])
         return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
 
+    def stream(self, batches, out_hw=None, on_forward=None):
+        """Software-pipelined loop over an iterable of (N,3,H,W) GPU batches: the forward
+        of batch k+1 is enqueued before the host part of batch k's decode (top-k read-back,
+        C++ matching, refine read-back) runs, and the decode kernels go to a side stream,
+        so the two overlap.  Yields one ``[(people, scores)] * N`` list per batch, in order.
+        ``on_forward(k, x)`` may replace the plain forward (bench.py records op events)."""
+        side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        pending = None
+
+        def decode(item):
+            (preds, refined), done, hw = item
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
+
+        with torch.no_grad():
+            for k, x in enumerate(batches):
+                out = on_forward(k, x) if on_forward is not None else self.model(x)
+                done = torch.cuda.Event()
+                done.record(main)
+                hw = tuple(out_hw) if out_hw is not None else tuple(x.shape[2:])
+                if pending is not None:
+                    yield decode(pending)
+                pending = (out, done, hw)
+            if pending is not None:
+                yield decode(pending)
+
     def gather(self, image_ids, results):
         """all-gather of the decoded keypoints over the process group (RCCL)"""
         import torch.distributed as dist
