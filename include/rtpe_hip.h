@@ -77,12 +77,15 @@ int rtpe_device_count(void);
 #define RTPE_F_OUT_REFINED 8 /* also write NCHW output 1 (refined)           */
 #define RTPE_F_NO_NHWC 16    /* skip the NHWC store (head whose only consumer
                                is the NCHW output)                            */
+#define RTPE_F_F32 32        /* the op works on fp32 tensors / weights (plain
+                               PoseHigherResolutionNet without the half
+                               wrapper; the students' fp32 part)              */
 
 typedef struct rtpe_tensor_desc {
   int32_t channels; /* allocated channels per pixel (the NHWC row length)     */
   int32_t ds_log2;  /* spatial size = (H >> ds_log2, W >> ds_log2)            */
   int32_t slot;     /* workspace slot (tensors with disjoint lifetimes share) */
-  int32_t reserved;
+  int32_t reserved; /* element size in bytes: 4 = fp32, anything else = fp16  */
 } rtpe_tensor_desc;
 
 typedef struct rtpe_op_desc {
@@ -99,7 +102,8 @@ typedef struct rtpe_op_desc {
   int32_t n_terms;         /* FUSE: number of terms                           */
   int32_t term_t[4];       /* FUSE: term tensor ids                           */
   int32_t term_up[4];      /* FUSE: log2 nearest-upsampling factor per term   */
-  int32_t reserved[3];
+  int32_t reserved[3];     /* [0] logical Cin for cost accounting (0: = cin);
+                              [1] dilation of a 3x3 conv (0: 1)               */
 } rtpe_op_desc;
 
 typedef struct rtpe_hrnet rtpe_hrnet;
@@ -175,6 +179,14 @@ int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin
                      const void* w_host, const float* alpha_host, const float* beta_host,
                      int32_t cout, int32_t ksize, int32_t stride, int32_t flags,
                      const void* res, void* y, void* stream);
+
+/* Same with dilation (3x3 stride 1 only; padding = dilation) and, with
+ * RTPE_F_F32 in flags, fp32 x / w_host / res / y (no intermediate rounding):
+ * the dilated fp32 convs of ContextAwareModule, rtpe/students.py:145-201. */
+int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
+                        const void* w_host, const float* alpha_host, const float* beta_host,
+                        int32_t cout, int32_t ksize, int32_t stride, int32_t dilation,
+                        int32_t flags, const void* res, void* y, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Decode: validate_hhrnet.py:94-98 + rtpe/third_party/group.py:125-287.

@@ -32,13 +32,45 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-constexpr int kTapTableBytes = 512;
+constexpr int kTapTableBytes = 1024;
 
 __device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }
 
-template <int MT, int NT, int WAVES>
+// storage precision: fp16 (the half wrapper: v_mfma_f32_16x16x32_f16, one fp16 rounding after
+// conv, BN and add) or fp32 (plain PoseHigherResolutionNet: v_mfma_f32_16x16x4_f32 = exact fp32
+// FMA chains, no intermediate rounding).  Both MFMAs share the C/D layout, hence the epilogue.
+template <typename T> struct Prec;
+template <> struct Prec<_Float16> {
+  static constexpr int EPS = 8;                                   // elements per 16-byte slot
+  static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+};
+template <> struct Prec<float> {
+  static constexpr int EPS = 4;
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+
+template <typename T>
+__device__ __forceinline__ float4v mfma_step(const uint4& av, const uint4& bv, float4v acc);
+template <>
+__device__ __forceinline__ float4v mfma_step<_Float16>(const uint4& av, const uint4& bv, float4v acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bv), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ float4v mfma_step<float>(const uint4& av, const uint4& bv, float4v acc) {
+  // element j of every lane group forms one k=4 step: channels {j, 4+j, 8+j, 12+j} of the chunk
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.x), __uint_as_float(bv.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.y), __uint_as_float(bv.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.z), __uint_as_float(bv.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.w), __uint_as_float(bv.w), acc, 0, 0, 0);
+  return acc;
+}
+
+template <typename T, int MT, int NT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPS = Prec<T>::EPS;
+  constexpr int KCH = 4 * EPS;                 // k values per k chunk: 32 (fp16) / 16 (fp32)
+  constexpr int ES = (int)sizeof(T);
 #ifdef RTPE_CONV_STAMPS
 #define RTPE_STAMP(i)                                   \
   do {                                                  \
@@ -76,13 +108,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   // LDS byte offset of (tap, channel) for every (k chunk, lane group)
   const int kvalid = a.ntaps * a.cc;
   for (int i = tid; i < a.kc * 4; i += NTHREADS) {
-    int kk = (i >> 2) * 32 + (i & 3) * 8;
+    int kk = (i >> 2) * KCH + (i & 3) * EPS;
     if (kk >= kvalid) kk -= kvalid;  // zero-weight padding: any finite in-tile data will do
     const int tap = fdiv(kk, a.div_cc);
     const int c = kk - tap * a.cc;
     const int tyy = (a.tapw == 3) ? (tap * 11 >> 5) : (a.tapw == 2 ? (tap >> 1) : 0);
     const int txx = tap - tyy * a.tapw;
-    tapoff[i] = (tyy * a.halo_w + txx) * a.pstride + c * 2;
+    tapoff[i] = (tyy * a.dil * a.halo_w + txx * a.dil) * a.pstride + c * ES;
   }
 
   // per-lane pixel of each N tile
@@ -102,16 +134,16 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
 
   const int n_k = a.n_cchunks * a.kc;  // total k chunks
-  const half8* wfrag = reinterpret_cast<const half8*>(a.w) + (size_t)cb * n_k * MT * 64 + lane;
+  const uint4* wfrag = reinterpret_cast<const uint4*>(a.w) + (size_t)cb * n_k * MT * 64 + lane;
 
-  half8 a_cur[MT];
+  uint4 a_cur[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) a_cur[m] = wfrag[m * 64];
 
-  const int slots = a.cc >> 3;               // 16-B slots per staged pixel
+  const int slots = a.cc / EPS;              // 16-B slots per staged pixel
   const int rowslots = a.halo_w * slots;     // per halo row
   const int total = a.halo_h * rowslots;
-  const _Float16* xin = a.x + (size_t)n * a.H_in * a.W_in * a.in_ld;
+  const T* xin = reinterpret_cast<const T*>(a.x) + (size_t)n * a.H_in * a.W_in * a.in_ld;
 
   int kf = 0;  // linear k-chunk index over (channel chunk, k chunk)
   RTPE_STAMP(1);
@@ -135,8 +167,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         dst[u] = idx < total ? (int)((hy * a.halo_w + hx) * a.pstride + s * 16) : -1;
         v[u] = make_uint4(0, 0, 0, 0);
         if (idx < total && (unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in &&
-            cbase + (int)s * 8 < a.cin)
-          v[u] = *reinterpret_cast<const uint4*>(xin + ((size_t)iy * a.W_in + ix) * a.in_ld + cbase + s * 8);
+            cbase + (int)s * EPS < a.cin)
+          v[u] = *reinterpret_cast<const uint4*>(xin + ((size_t)iy * a.W_in + ix) * a.in_ld + cbase + s * EPS);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -147,20 +179,19 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
     // ---- k loop over [tap][channel] of this chunk ----
     for (int kci = 0; kci < a.kc; ++kci, ++kf) {
-      half8 a_nxt[MT];
+      uint4 a_nxt[MT];
       const int kn = (kf + 1 < n_k) ? kf + 1 : kf;
 #pragma unroll
       for (int m = 0; m < MT; ++m) a_nxt[m] = wfrag[(size_t)(kn * MT + m) * 64];
       const int off = tapoff[kci * 4 + g];
-      half8 b[NT];
+      uint4 b[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        b[nt] = *reinterpret_cast<const half8*>(tile + pixbase[nt] + off);
+        b[nt] = *reinterpret_cast<const uint4*>(tile + pixbase[nt] + off);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[m], b[nt], acc[m][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_step<T>(a_cur[m], b[nt], acc[m][nt]);
 #pragma unroll
       for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
     }
@@ -181,30 +212,32 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
   }
   // The accumulator layout (4 channels of one pixel per lane) would make the NHWC
-  // store and the residual load 8-byte pieces scattered over 16 rows per
+  // store and the residual load small pieces scattered over 16 rows per
   // instruction.  Instead each wave transposes its 16*NT pixels x 16*MT channels
   // through its own slice of the (now free) input-tile LDS and then moves whole
   // rows with 16-byte accesses: consecutive lanes cover consecutive bytes of a
   // pixel row, consecutive pixels of a tile row are contiguous in NHWC.
-  constexpr int ROWB = MT * 32 + 16;      // LDS bytes per pixel row (+16: spreads the b64 writes over banks)
-  constexpr int CH = MT * 2;              // 16-byte chunks per pixel row
-  __syncthreads();                        // every wave is done reading the input tile
+  constexpr int ROWB = MT * 16 * ES + 16;  // LDS bytes per pixel row (+16: spreads the writes over banks)
+  constexpr int CH = MT * 16 / EPS;        // 16-byte chunks per pixel row
+  __syncthreads();                         // every wave is done reading the input tile
   char* obuf = tile + wv * (NT * 16 * ROWB);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       float4v v = acc[m][nt];
-      half4 o;
+      T o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = v[j];
-        if (a.round_conv) x = round16(x);
-        x = round16(__builtin_fmaf(x, al[m][j], be[m][j]));
+        if (a.round_conv) x = Prec<T>::rnd(x);
+        x = Prec<T>::rnd(__builtin_fmaf(x, al[m][j], be[m][j]));
         v[j] = x;
-        o[j] = (_Float16)x;
+        o[j] = (T)x;
       }
-      *reinterpret_cast<half4*>(obuf + (nt * 16 + r) * ROWB + m * 32 + g * 8) = o;
+      T* orow = reinterpret_cast<T*>(obuf + (nt * 16 + r) * ROWB) + m * 16 + g * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) orow[j] = o[j];
       if (a.y_nchw != nullptr) {          // heads: NCHW fp32/fp16 straight from the registers
         const uint32_t p = (wv * NT + nt) * 16 + r;
         const uint32_t oyt = fdiv(p, a.div_tw);
@@ -231,6 +264,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   }
   if (a.y != nullptr) {
     const int cblk = cb * MT * 16;
+    T* yout = reinterpret_cast<T*>(a.y);
+    const T* rin = reinterpret_cast<const T*>(a.res);
 #pragma unroll
     for (int it = 0; it < (NT * 16 * CH + 63) / 64; ++it) {
       const int c = it * 64 + lane;                 // chunk index inside this wave's pixels
@@ -240,21 +275,26 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       const uint32_t oyt = fdiv(p, a.div_tw);
       const uint32_t oxt = p - oyt * a.tw;
       const int py = py0 + (int)oyt, px = px0 + (int)oxt;
-      const int ch = cblk + slot * 8;
+      const int ch = cblk + slot * EPS;
       if (py >= a.H_pos || px >= a.W_pos || ch >= a.cout_store) continue;
       const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
       const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
-      half8 v = *reinterpret_cast<const half8*>(obuf + pw * ROWB + slot * 16);
-      if (a.res != nullptr) {
-        const half8 rr = *reinterpret_cast<const half8*>(a.res + pix * a.res_ld + ch);
+      uint4 raw = *reinterpret_cast<const uint4*>(obuf + pw * ROWB + slot * 16);
+      T v[EPS];
+      __builtin_memcpy(v, &raw, 16);
+      if (rin != nullptr) {
+        const uint4 rraw = *reinterpret_cast<const uint4*>(rin + pix * a.res_ld + ch);
+        T rr[EPS];
+        __builtin_memcpy(rr, &rraw, 16);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] + (float)rr[j]);
+        for (int j = 0; j < EPS; ++j) v[j] = (T)((float)v[j] + (float)rr[j]);
       }
       if (a.relu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0.f ? v[j] : (_Float16)0.f;
+        for (int j = 0; j < EPS; ++j) v[j] = v[j] > (T)0.f ? v[j] : (T)0.f;
       }
-      *reinterpret_cast<half8*>(a.y + pix * a.out_ld + ch) = v;
+      __builtin_memcpy(&raw, v, 16);
+      *reinterpret_cast<uint4*>(yout + pix * a.out_ld + ch) = raw;
     }
   }
 #ifdef RTPE_CONV_STAMPS
@@ -292,8 +332,19 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
   if (g.cout <= 32) p.mt = (g.cout + 15) / 16;
   p.cout_pad = round_up(g.cout, 16 * p.mt);
   p.n_cb = p.cout_pad / (16 * p.mt);
-  const int cin8 = round_up(g.cin, 8);
-  if (p.tapw == 1) {
+  const int eps = 16 / (g.esize ? g.esize : 2);          // elements per 16-byte slot
+  const int kch = 4 * eps;                               // k values per k chunk
+  p.esize = g.esize ? g.esize : 2;
+  p.dil = g.dil > 0 ? g.dil : 1;
+  if (!dc) p.lo_y = p.lo_x = -(g.ksize / 2) * p.dil;
+  const int cin8 = round_up(g.cin, eps);
+  if (p.esize == 4) {
+    // fp32: chunks of 48 / 64 / 32 / 16 channels (multiples of the 16-channel k chunk)
+    if (cin8 % 48 == 0) p.cc = 48;
+    else if (cin8 % 64 == 0) p.cc = 64;
+    else if (cin8 % 32 == 0) p.cc = 32;
+    else p.cc = round_up(cin8 < 64 ? cin8 : 48, 16);
+  } else if (p.tapw == 1) {
     // 1x1: largest chunk <= 128 that divides cin and is a multiple of 32
     p.cc = 0;
     for (int c = 128; c >= 32; c -= 32)
@@ -306,41 +357,45 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
     else p.cc = round_up(cin8 < 64 ? cin8 : 48, 16);
   }
   p.n_cchunks = (cin8 + p.cc - 1) / p.cc;
-  p.kc = (p.tapw * p.tapw * p.cc + 31) / 32;
-  p.pstride = p.cc * 2;
+  p.kc = (p.tapw * p.tapw * p.cc + kch - 1) / kch;
+  p.pstride = p.cc * p.esize;
   while (p.pstride % 64 != 32) p.pstride += 16;
-  p.packed_bytes = (size_t)p.n_cb * p.n_cchunks * p.kc * p.mt * 64 * 8 * sizeof(uint16_t);
+  p.packed_bytes = (size_t)p.n_cb * p.n_cchunks * p.kc * p.mt * 64 * 16;
   return p;
 }
 
-void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const uint16_t* w, uint16_t* packed) {
+void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w_in, void* packed_out) {
   const int ntaps = p.tapw * p.tapw;
   const bool dc = g.deconv_class >= 0;
   const int ca = dc ? (g.deconv_class >> 1) : 0, cbb = dc ? (g.deconv_class & 1) : 0;
+  const int es = p.esize, eps = 16 / es, kch = 4 * eps;
+  const char* w = reinterpret_cast<const char*>(w_in);
+  char* packed = reinterpret_cast<char*>(packed_out);
   size_t o = 0;
   for (int cb = 0; cb < p.n_cb; ++cb)
     for (int cci = 0; cci < p.n_cchunks; ++cci)
       for (int kci = 0; kci < p.kc; ++kci)
         for (int m = 0; m < p.mt; ++m)
           for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j, ++o) {
+            for (int j = 0; j < eps; ++j, o += es) {
               const int co = (cb * p.mt + m) * 16 + (lane & 15);
-              const int kk = kci * 32 + 8 * (lane >> 4) + j;
+              const int kk = kci * kch + eps * (lane >> 4) + j;
               const int tap = kk / p.cc, c = cci * p.cc + kk % p.cc;
-              uint16_t v = 0;
+              memset(packed + o, 0, es);
               if (tap < ntaps && co < g.cout && c < g.cin) {
                 const int ty = tap / p.tapw, tx = tap % p.tapw;
+                size_t src;
                 if (!dc) {
-                  v = w[(((size_t)co * g.cin + c) * g.ksize + ty) * g.ksize + tx];
+                  src = (((size_t)co * g.cin + c) * g.ksize + ty) * g.ksize + tx;
                 } else {
                   // oy = 2*iy - 1 + ky  =>  class a=0: dy=-1 -> ky=3, dy=0 -> ky=1
                   //                         class a=1: dy=0  -> ky=2, dy=+1 -> ky=0
                   const int ky = ca == 0 ? (ty == 0 ? 3 : 1) : (ty == 0 ? 2 : 0);
                   const int kx = cbb == 0 ? (tx == 0 ? 3 : 1) : (tx == 0 ? 2 : 0);
-                  v = w[(((size_t)c * g.cout + co) * 4 + ky) * 4 + kx];  // IOHW
+                  src = (((size_t)c * g.cout + co) * 4 + ky) * 4 + kx;  // IOHW
                 }
+                memcpy(packed + o, w + src * es, es);
               }
-              packed[o] = v;
             }
 }
 
@@ -352,9 +407,9 @@ static const TileCand kCands[] = {
 };
 
 static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
-  const int hh = (th - 1) * p.in_mul + p.tapw, hw = (tw - 1) * p.in_mul + p.tapw;
+  const int hh = (th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1, hw = (tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   const size_t in_tile = (size_t)hh * hw * p.pstride;
-  const size_t out_tile = (size_t)waves * nt * 16 * (p.mt * 32 + 16);   // epilogue transpose buffer
+  const size_t out_tile = (size_t)waves * nt * 16 * (p.mt * 16 * p.esize + 16);   // epilogue transpose buffer
   return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
 }
 
@@ -411,7 +466,7 @@ static ConvTile make_persist_tile(const ConvPlan& p, int N, int H_pos, int W_pos
 
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   static const int persist = getenv("RTPE_CONV_PERSIST") ? atoi(getenv("RTPE_CONV_PERSIST")) : 1;
-  if (persist && p.cc == 48 && p.pstride == 96) {
+  if (persist && p.esize == 2 && p.dil == 1 && p.cc == 48 && p.pstride == 96) {
     ConvTile t = make_persist_tile(p, N, H_pos, W_pos);
     if (t.nt) return t;
   }
@@ -435,8 +490,8 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
     double score = waste;
     if (wgs < 512) score *= 1.0 + 0.25 * (512.0 - wgs) / 512.0;
     score *= 1.0 + 0.4 / c.nt;
-    const double halo = (double)((c.th - 1) * p.in_mul + p.tapw) * ((c.tw - 1) * p.in_mul + p.tapw) /
-                        ((double)c.th * c.tw * p.in_mul * p.in_mul);
+    const double halo = (double)((c.th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1) *
+                        ((c.tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1) / ((double)c.th * c.tw * p.in_mul * p.in_mul);
     score *= 1.0 + 0.1 * (halo - 1.0);
     if (score < best_score) {
       best_score = score;
@@ -453,13 +508,14 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->in_mul = p.in_mul;
   a->cc = p.cc; a->n_cchunks = p.n_cchunks; a->kc = p.kc; a->pstride = p.pstride;
   a->th = t.th; a->tw = t.tw;
-  a->halo_h = (t.th - 1) * p.in_mul + p.tapw;
-  a->halo_w = (t.tw - 1) * p.in_mul + p.tapw;
+  a->dil = p.dil;
+  a->halo_h = (t.th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
+  a->halo_w = (t.tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   a->tiles_x = (a->W_pos + t.tw - 1) / t.tw;
   a->tiles_y = (a->H_pos + t.th - 1) / t.th;
   a->div_tw = make_fastdiv(t.tw);
-  a->div_slots = make_fastdiv(p.cc / 8);
-  a->div_rowslots = make_fastdiv(a->halo_w * (p.cc / 8));
+  a->div_slots = make_fastdiv(p.cc / (16 / p.esize));
+  a->div_rowslots = make_fastdiv(a->halo_w * (p.cc / (16 / p.esize)));
   a->div_cc = make_fastdiv(p.cc);
   a->div_tiles_x = make_fastdiv(a->tiles_x);
   a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
@@ -470,10 +526,10 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   if (skipk) a->kc = 0;
 }
 
-template <int MT, int NT, int WAVES>
+template <typename T, int MT, int NT, int WAVES>
 static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_kernel<MT, NT, WAVES>;
+  auto kern = conv_mfma_kernel<T, MT, NT, WAVES>;
   if (!attr_set) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -508,7 +564,7 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     t.nt = c.nt; t.waves = c.waves; t.th = c.th; t.tw = c.tw;
     t.lds_bytes = tile_lds(p, c.th, c.tw, c.waves, c.nt);
     if (t.lds_bytes <= 160 * 1024) out->push_back(t);              // one workgroup per tile
-    if (p.cc == 48 && p.pstride == 96 && c.nt <= 5) {              // persistent + loader wave
+    if (p.esize == 2 && p.dil == 1 && p.cc == 48 && p.pstride == 96 && c.nt <= 5) {   // persistent + loader wave
       size_t buf = in_tile > out_tile ? in_tile : out_tile;
       buf = (buf + 1023) / 1024 * 1024;
       const size_t lds = kTapTableBytes + 2 * buf;
@@ -534,14 +590,17 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves, "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
   RTPE_REQUIRE(a.kc * 4 * sizeof(int) <= (size_t)kTapTableBytes, "k chunk table overflow (kc=%d)", a.kc);
-  RTPE_REQUIRE(a.in_ld % 8 == 0 && (a.y == nullptr || (a.out_ld % 8 == 0 && a.cout_store % 8 == 0 &&
-                                                       ((uintptr_t)a.y & 15) == 0)),
-               "conv: NHWC views must be 16-byte aligned with channel counts that are multiples of 8");
-  RTPE_REQUIRE(a.res == nullptr || (a.res_ld % 8 == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
+  const int eps = 16 / p.esize;
+  RTPE_REQUIRE(a.in_ld % eps == 0 && (a.y == nullptr || (a.out_ld % eps == 0 && a.cout_store % eps == 0 &&
+                                                         ((uintptr_t)a.y & 15) == 0)),
+               "conv: NHWC views must be 16-byte aligned with channel counts that are multiples of %d", eps);
+  RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 1) return conv_persist_launch(p, t, a, s);
-#define RTPE_V(MTv, NTv, Wv) \
-  if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_variant<MTv, NTv, Wv>(t, a, p.n_cb, s);
+#define RTPE_V(MTv, NTv, Wv)                                                                  \
+  if (p.mt == MTv && t.nt == NTv && t.waves == Wv)                                            \
+    return p.esize == 4 ? launch_variant<float, MTv, NTv, Wv>(t, a, p.n_cb, s)                 \
+                        : launch_variant<_Float16, MTv, NTv, Wv>(t, a, p.n_cb, s);
   RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5)
   RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5)
   RTPE_V(2, 8, 4) RTPE_V(2, 4, 4) RTPE_V(2, 2, 4) RTPE_V(2, 5, 4) RTPE_V(2, 5, 5)

@@ -16,8 +16,10 @@ __device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }
 // (nn.Upsample(scale_factor=2**(j-i), mode='nearest'), :209), i.e. the
 // upsampled tensor is never written to HBM.
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
-  const int c8 = a.C >> 3;
+  constexpr int EPS = 16 / (int)sizeof(T);       // elements per 16-byte access
+  const int c8 = a.C / EPS;
   const size_t total = (size_t)a.N * a.H * a.W * c8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -27,30 +29,38 @@ __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
     pix /= a.W;
     const int y = (int)(pix % a.H);
     const int n = (int)(pix / a.H);
-    float acc[8];
+    float acc[EPS];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t >= a.n_terms) break;
       const int u = a.term_up[t];
       const int hs = a.H >> u, ws = a.W >> u;
-      const half8 v = *reinterpret_cast<const half8*>(
-          a.term[t] + (((size_t)n * hs + (y >> u)) * ws + (x >> u)) * a.term_ld[t] + cs * 8);
+      const uint4 raw = *reinterpret_cast<const uint4*>(
+          reinterpret_cast<const T*>(a.term[t]) + (((size_t)n * hs + (y >> u)) * ws + (x >> u)) * a.term_ld[t] + cs * EPS);
+      T v[EPS];
+      __builtin_memcpy(v, &raw, 16);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = t == 0 ? (float)v[j] : round16(acc[j] + (float)v[j]);
+      for (int j = 0; j < EPS; ++j) acc[j] = t == 0 ? (float)v[j] : (float)(T)(acc[j] + (float)v[j]);
     }
-    half8 o;
+    T o[EPS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(acc[j] > 0.f ? acc[j] : 0.f);
-    *reinterpret_cast<half8*>(a.y + (((size_t)n * a.H + y) * a.W + x) * a.out_ld + cs * 8) = o;
+    for (int j = 0; j < EPS; ++j) o[j] = (T)(acc[j] > 0.f ? acc[j] : 0.f);
+    uint4 oraw;
+    __builtin_memcpy(&oraw, o, 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + (((size_t)n * a.H + y) * a.W + x) * a.out_ld + cs * EPS) = oraw;
   }
 }
 
 int fuse_launch(const FuseArgs& a, hipStream_t s) {
-  RTPE_REQUIRE(a.C % 8 == 0 && a.n_terms >= 1 && a.n_terms <= 4, "fuse: C=%d terms=%d", a.C, a.n_terms);
-  const size_t total = (size_t)a.N * a.H * a.W * (a.C / 8);
+  const int eps = a.f32 ? 4 : 8;
+  RTPE_REQUIRE(a.C % eps == 0 && a.n_terms >= 1 && a.n_terms <= 4, "fuse: C=%d terms=%d", a.C, a.n_terms);
+  const size_t total = (size_t)a.N * a.H * a.W * (a.C / eps);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(fuse_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  if (a.f32)
+    hipLaunchKernelGGL(fuse_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(fuse_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;
 }
@@ -64,7 +74,9 @@ int fuse_launch(const FuseArgs& a, hipStream_t s) {
 constexpr int kStemTH = 8, kStemTW = 32, kStemCO = 64;
 constexpr int kStemPH = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 1;
 
+template <typename T>
 __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
+  constexpr bool kHalf = sizeof(T) == 2;
   __shared__ float patch[3][kStemPH][kStemPW + 1];
   __shared__ __attribute__((aligned(16))) float wl[27][kStemCO];
   const int Ho = a.H >> 1, Wo = a.W >> 1;
@@ -77,7 +89,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
   const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < 27 * kStemCO; i += 256) wl[i / kStemCO][i % kStemCO] = (float)a.w[i];
+  for (int i = tid; i < 27 * kStemCO; i += 256) wl[i / kStemCO][i % kStemCO] = (float)reinterpret_cast<const T*>(a.w)[i];
   for (int i = tid; i < 3 * kStemPH * kStemPW; i += 256) {
     const int c = i / (kStemPH * kStemPW);
     const int rem = i - c * kStemPH * kStemPW;
@@ -86,8 +98,8 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
     float v = 0.f;
     if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
       const size_t o = (((size_t)n * 3 + c) * a.H + iy) * a.W + ix;
-      v = a.x_f32 ? round16(reinterpret_cast<const float*>(a.x)[o])
-                  : (float)reinterpret_cast<const _Float16*>(a.x)[o];
+      v = a.x_f32 ? reinterpret_cast<const float*>(a.x)[o] : (float)reinterpret_cast<const _Float16*>(a.x)[o];
+      if (kHalf) v = round16(v);                          // tofp16 of the half wrapper
     }
     patch[c][py][px] = v;
   }
@@ -116,18 +128,22 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
         }
       }
   if (oy < Ho && ox < Wo) {
-    _Float16* dst = a.y + (((size_t)n * Ho + oy) * Wo + ox) * a.out_ld;
+    T* dst = reinterpret_cast<T*>(a.y) + (((size_t)n * Ho + oy) * Wo + ox) * a.out_ld;
+    constexpr int EPS = 16 / (int)sizeof(T);
 #pragma unroll
-    for (int q = 0; q < kStemCO / 8; ++q) {
-      half8 o;
+    for (int q = 0; q < kStemCO / EPS; ++q) {
+      T o[EPS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int co = q * 8 + j;
-        float v = round16(acc[co]);                                   // conv output (fp16)
-        v = round16(__builtin_fmaf(v, a.alpha[co], a.beta[co]));      // BN output (fp16)
-        o[j] = (_Float16)(v > 0.f ? v : 0.f);
+      for (int j = 0; j < EPS; ++j) {
+        const int co = q * EPS + j;
+        float v = kHalf ? round16(acc[co]) : acc[co];                 // conv output
+        v = __builtin_fmaf(v, a.alpha[co], a.beta[co]);               // BN output
+        if (kHalf) v = round16(v);
+        o[j] = (T)(v > 0.f ? v : 0.f);
       }
-      *reinterpret_cast<half8*>(dst + q * 8) = o;
+      uint4 raw;
+      __builtin_memcpy(&raw, o, 16);
+      *reinterpret_cast<uint4*>(dst + q * EPS) = raw;
     }
   }
 }
@@ -136,7 +152,10 @@ int stem_launch(const StemArgs& a, hipStream_t s) {
   RTPE_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0 && a.out_ld % 8 == 0, "stem: H=%d W=%d", a.H, a.W);
   const int Ho = a.H / 2, Wo = a.W / 2;
   const int tiles = ((Wo + kStemTW - 1) / kStemTW) * ((Ho + kStemTH - 1) / kStemTH);
-  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(tiles * a.N)), dim3(256), 0, s, a);
+  if (a.f32)
+    hipLaunchKernelGGL(stem_kernel<float>, dim3((unsigned)(tiles * a.N)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(stem_kernel<_Float16>, dim3((unsigned)(tiles * a.N)), dim3(256), 0, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;
 }

@@ -98,21 +98,22 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
       o.n_geom = d.kind == RTPE_OP_DECONV ? 4 : 1;
       for (int k = 0; k < o.n_geom; ++k) {
-        o.geom[k] = ConvGeom{d.cin, d.cout, d.ksize, d.stride, d.kind == RTPE_OP_DECONV ? k : -1};
+        o.geom[k] = ConvGeom{d.cin, d.cout, d.ksize, d.stride, d.kind == RTPE_OP_DECONV ? k : -1,
+                             (d.flags & RTPE_F_F32) ? 4 : 2, d.reserved[1] > 0 ? d.reserved[1] : 1};
         o.plan[k] = conv_make_plan(o.geom[k]);
         o.w_dev_off[k] = off;
         off = align_up(off + o.plan[k].packed_bytes, 256);
       }
       o.ab_dev_off = off;
       off = align_up(off + 2 * sizeof(float) * o.plan[0].cout_pad, 256);
-      const size_t wbytes = (size_t)d.cin * d.cout * d.ksize * d.ksize * 2;
+      const size_t wbytes = (size_t)d.cin * d.cout * d.ksize * d.ksize * ((d.flags & RTPE_F_F32) ? 4 : 2);
       if (d.w_off < 0 || (size_t)d.w_off + wbytes > weights_bytes ||
           d.ab_off < 0 || (size_t)d.ab_off + 8 * (size_t)d.cout > weights_bytes) {
         set_error("op %d: weight offsets out of range", i); delete h; return RTPE_E_INVALID;
       }
     } else if (d.kind == RTPE_OP_STEM) {
       o.w_dev_off[0] = off;
-      off = align_up(off + 27 * 64 * 2, 256);
+      off = align_up(off + 27 * 64 * 4, 256);
       o.ab_dev_off = off;
       off = align_up(off + 2 * sizeof(float) * 64, 256);
       if (d.cout != 64 || d.cin != 3) { set_error("stem must be 3->64"); delete h; return RTPE_E_INVALID; }
@@ -131,20 +132,21 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     const rtpe_op_desc& d = o.d;
     if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
       for (int k = 0; k < o.n_geom; ++k)
-        conv_pack_weights(o.geom[k], o.plan[k], reinterpret_cast<const uint16_t*>(wb + d.w_off),
-                          reinterpret_cast<uint16_t*>(host.data() + o.w_dev_off[k]));
+        conv_pack_weights(o.geom[k], o.plan[k], wb + d.w_off, host.data() + o.w_dev_off[k]);
       float* ab = reinterpret_cast<float*>(host.data() + o.ab_dev_off);
       const float* src = reinterpret_cast<const float*>(wb + d.ab_off);
       const int cp = o.plan[0].cout_pad;
       for (int c = 0; c < d.cout; ++c) { ab[c] = src[c]; ab[cp + c] = src[d.cout + c]; }
     } else if (d.kind == RTPE_OP_STEM) {
-      const uint16_t* w = reinterpret_cast<const uint16_t*>(wb + d.w_off);  // (64,3,3,3)
-      uint16_t* p = reinterpret_cast<uint16_t*>(host.data() + o.w_dev_off[0]);
+      const int es = (d.flags & RTPE_F_F32) ? 4 : 2;                 // (64,3,3,3) in the program's precision
+      const char* w = wb + d.w_off;
+      char* p = host.data() + o.w_dev_off[0];
       for (int co = 0; co < 64; ++co)
         for (int c = 0; c < 3; ++c)
           for (int ky = 0; ky < 3; ++ky)
             for (int kx = 0; kx < 3; ++kx)
-              p[((ky * 3 + kx) * 3 + c) * 64 + co] = w[((co * 3 + c) * 3 + ky) * 3 + kx];
+              memcpy(p + (size_t)(((ky * 3 + kx) * 3 + c) * 64 + co) * es,
+                     w + (size_t)(((co * 3 + c) * 3 + ky) * 3 + kx) * es, es);
       memcpy(host.data() + o.ab_dev_off, wb + d.ab_off, 2 * 64 * sizeof(float));
     }
   }
@@ -168,7 +170,7 @@ extern "C" int rtpe_hrnet_destroy(rtpe_hrnet* h) {
 static void slot_layout(const rtpe_hrnet* h, int N, int H, int W, std::vector<size_t>* offs, size_t* total) {
   std::vector<size_t> sz(h->n_slots, 0);
   for (const auto& t : h->tensors) {
-    const size_t b = (size_t)N * (H >> t.ds_log2) * (W >> t.ds_log2) * t.channels * 2;
+    const size_t b = (size_t)N * (H >> t.ds_log2) * (W >> t.ds_log2) * t.channels * (t.reserved == 4 ? 4 : 2);
     if (b > sz[t.slot]) sz[t.slot] = b;
   }
   offs->resize(h->n_slots);
@@ -199,8 +201,9 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
   if (need > ws_bytes) { set_error("forward: workspace %zu < %zu", ws_bytes, need); return RTPE_E_NOMEM; }
   RTPE_REQUIRE(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
   char* base = reinterpret_cast<char*>(ws);
-  auto tptr = [&](int t, int coff) -> _Float16* {
-    return reinterpret_cast<_Float16*>(base + offs[h->tensors[t].slot]) + coff;
+  auto esz = [&](int t) -> size_t { return h->tensors[t].reserved == 4 ? 4 : 2; };
+  auto tptr = [&](int t, int coff) -> _Float16* {      // element type per tensor (fp16 or fp32): byte arithmetic
+    return reinterpret_cast<_Float16*>(base + offs[h->tensors[t].slot] + (size_t)coff * esz(t));
   };
   std::vector<hipEvent_t> ev;
   const bool timed = op_ms != nullptr;
@@ -237,6 +240,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.beta = a.alpha + 64;
       a.y = tptr(d.out_t, d.out_coff);
       a.N = N; a.H = H; a.W = W; a.out_ld = to.channels;
+      a.f32 = (d.flags & RTPE_F_F32) ? 1 : 0;
       rc = stem_launch(a, s);
     } else if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
       const rtpe_tensor_desc& ti = h->tensors[d.in_t];
@@ -249,7 +253,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         memset(&a, 0, sizeof(a));
         a.x = tptr(d.in_t, d.in_coff);
         a.in_ld = ti.channels;
-        a.x_bytes = (size_t)N * Hi * Wi * ti.channels * 2 - (size_t)d.in_coff * 2;
+        a.x_bytes = ((size_t)N * Hi * Wi * ti.channels - (size_t)d.in_coff) * esz(d.in_t);
         a.w = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[k]);
         a.alpha = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
         a.beta = a.alpha + o.plan[0].cout_pad;
@@ -302,6 +306,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.y = tptr(d.out_t, d.out_coff);
       a.out_ld = to.channels; a.C = d.cout;
       a.N = N; a.H = H >> to.ds_log2; a.W = W >> to.ds_log2;
+      a.f32 = (d.flags & RTPE_F_F32) ? 1 : 0;
       rc = fuse_launch(a, s);
     }
     if (rc != RTPE_OK) return rc;
@@ -363,19 +368,21 @@ extern "C" int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, in
 }
 
 // ---- single-layer entry (layer-level parity tests) -------------------------
-extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
-                                const void* w_host, const float* alpha_host, const float* beta_host,
-                                int32_t cout, int32_t ksize, int32_t stride, int32_t flags, const void* res,
-                                void* y, void* stream) {
+extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
+                                   const void* w_host, const float* alpha_host, const float* beta_host,
+                                   int32_t cout, int32_t ksize, int32_t stride, int32_t dilation, int32_t flags,
+                                   const void* res, void* y, void* stream) {
   RTPE_REQUIRE(x && w_host && alpha_host && beta_host && y, "conv2d_nhwc: null argument");
-  RTPE_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin % 8 == 0 && cout % 8 == 0,
-               "conv2d_nhwc: k=%d s=%d cin=%d cout=%d unsupported", ksize, stride, cin, cout);
+  const int es = (flags & RTPE_F_F32) ? 4 : 2, eps = 16 / es;
+  RTPE_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin % eps == 0 && cout % eps == 0 &&
+                   dilation >= 1 && (dilation == 1 || (ksize == 3 && stride == 1)),
+               "conv2d_nhwc: k=%d s=%d d=%d cin=%d cout=%d unsupported", ksize, stride, dilation, cin, cout);
   RTPE_REQUIRE(H % stride == 0 && W % stride == 0, "conv2d_nhwc: H, W must be multiples of the stride");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  ConvGeom g{cin, cout, ksize, stride, -1};
+  ConvGeom g{cin, cout, ksize, stride, -1, es, dilation};
   ConvPlan p = conv_make_plan(g);
-  std::vector<uint16_t> packed(p.packed_bytes / 2);
-  conv_pack_weights(g, p, reinterpret_cast<const uint16_t*>(w_host), packed.data());
+  std::vector<char> packed(p.packed_bytes);
+  conv_pack_weights(g, p, w_host, packed.data());
   std::vector<float> ab(2 * p.cout_pad, 0.f);
   for (int c = 0; c < cout; ++c) { ab[c] = alpha_host[c]; ab[p.cout_pad + c] = beta_host[c]; }
   char* dev = nullptr;
@@ -387,7 +394,7 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.x = reinterpret_cast<const _Float16*>(x); a.in_ld = cin;
-  a.x_bytes = (size_t)N * H * W * cin * 2;
+  a.x_bytes = (size_t)N * H * W * cin * es;
   a.w = reinterpret_cast<const _Float16*>(dev);
   a.alpha = reinterpret_cast<const float*>(dev + wb); a.beta = a.alpha + p.cout_pad;
   a.res = reinterpret_cast<const _Float16*>(res); a.res_ld = cout;
@@ -405,7 +412,7 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
   a.dbg = dbg;
 #endif
   int rc = conv_launch(p, tile, a, s);
-  hipError_t es = hipStreamSynchronize(s);
+  hipError_t es2 = hipStreamSynchronize(s);
 #ifdef RTPE_CONV_STAMPS
   unsigned long long hd[16];
   hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost);
@@ -419,8 +426,16 @@ extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, 
 #endif
   hipFree(dev);
   if (rc != RTPE_OK) return rc;
-  if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
+  if (es2 != hipSuccess) return hip_fail(es2, "hipStreamSynchronize", __FILE__, __LINE__);
   return RTPE_OK;
+}
+
+extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
+                                const void* w_host, const float* alpha_host, const float* beta_host,
+                                int32_t cout, int32_t ksize, int32_t stride, int32_t flags, const void* res,
+                                void* y, void* stream) {
+  return rtpe_conv2d_nhwc_ex(x, N, H, W, cin, w_host, alpha_host, beta_host, cout, ksize, stride, 1,
+                             flags & ~RTPE_F_F32, res, y, stream);
 }
 
 // introspection for bench / tuning: kernel variant and geometry of a conv op

@@ -63,7 +63,8 @@ struct ConvArgs {
   int cout_store;        // channels written to NHWC (multiple of 4 groups masked)
   int nchw_channels;     // channel count of the NCHW output
   int nchw_f32;          // 1: fp32 NCHW, 0: fp16
-  int tapw, ntaps;       // taps form a tapw x tapw grid: (dy,dx) = (lo_y+ty, lo_x+tx)
+  int tapw, ntaps;       // taps form a tapw x tapw grid: (dy,dx) = (lo_y+ty*dil, lo_x+tx*dil)
+  int dil;               // dilation
   int lo_y, lo_x;        // min tap offsets
   int halo_h, halo_w;    // staged input tile (pixels)
   int cc;                // input channels staged per chunk
@@ -84,6 +85,7 @@ struct ConvPlan {       // weight-layout half of the plan (fixed at create time)
   int mt;               // cout tiles (x16) per wave = per workgroup
   int cc, kc, n_cchunks, pstride;
   int tapw, in_mul, lo_y, lo_x;
+  int esize, dil;       // bytes per element (2 fp16 / 4 fp32), dilation
   int cout_pad, n_cb;   // cout rounded up to 16*mt; number of cout blocks
   size_t packed_bytes;  // bytes of packed weights (all cout blocks)
 };
@@ -100,6 +102,8 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
 struct ConvGeom {       // logical layer, independent of the batch
   int cin, cout, ksize, stride;
   int deconv_class;     // -1: plain conv; 0..3: k4 s2 p1 transposed-conv parity class (a*2+b)
+  int esize;            // 2 (fp16, default when 0) or 4 (fp32)
+  int dil;              // dilation (default 1 when 0); padding = dil * (ksize / 2)
 };
 
 ConvPlan conv_make_plan(const ConvGeom& g);
@@ -107,8 +111,7 @@ ConvPlan conv_make_plan(const ConvGeom& g);
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos);
 void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector<ConvTile>* out);
 // pack fp16 weights (host) into fragment order; w is OIHW (IOHW 4x4 for deconv classes)
-void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const uint16_t* w,
-                       uint16_t* packed);
+void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w, void* packed);
 // fill geometry / divisors of `a` (pointers, sizes and flags are the caller's)
 void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, ConvArgs* a);
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
@@ -122,6 +125,7 @@ struct FuseArgs {
   _Float16* y;
   int out_ld, C;
   int N, H, W;  // output spatial size
+  int f32;      // 1: fp32 tensors (pointers are reinterpreted), 0: fp16
 };
 int fuse_launch(const FuseArgs& a, hipStream_t s);
 
@@ -133,6 +137,7 @@ struct StemArgs {
   const float* beta;
   _Float16* y;  // NHWC (N,H/2,W/2,64)
   int N, H, W, out_ld;
+  int f32;      // 1: fp32 weights / output, no intermediate rounding
 };
 int stem_launch(const StemArgs& a, hipStream_t s);
 

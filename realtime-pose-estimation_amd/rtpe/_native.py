@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "librtpe_hip.so")
 
 RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
 OP_STEM, OP_CONV, OP_DECONV, OP_FUSE = 0, 1, 2, 3
-F_RELU, F_ROUND_CONV, F_OUT_PREDS, F_OUT_REFINED, F_NO_NHWC = 1, 2, 4, 8, 16
+F_RELU, F_ROUND_CONV, F_OUT_PREDS, F_OUT_REFINED, F_NO_NHWC, F_F32 = 1, 2, 4, 8, 16, 32
 
 
 class TensorDesc(Structure):
@@ -57,6 +57,9 @@ _SIGS = {
     "rtpe_conv2d_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    POINTER(c_float), POINTER(c_float), c_int32, c_int32, c_int32,
                                    c_int32, c_void_p, c_void_p, c_void_p]),
+    "rtpe_conv2d_nhwc_ex": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                      POINTER(c_float), POINTER(c_float), c_int32, c_int32, c_int32,
+                                      c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rtpe_bilinear_upsample": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32,
                                          c_int32, c_void_p]),
     "rtpe_nms": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

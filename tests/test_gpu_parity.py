@@ -112,6 +112,71 @@ def test_conv_layer(nat, case):
     assert same > 0.97, "only %.4f identical" % same
 
 
+FP32_CONV_CASES = [
+    # cin, cout, k, stride, dilation, H, W, residual, relu   (fp32; dilated = ContextAwareModule, students.py:145-201)
+    (48, 48, 3, 1, 1, 24, 40, True, True), (96, 192, 3, 2, 1, 32, 32, False, True),
+    (64, 256, 1, 1, 1, 16, 24, True, True), (112, 32, 3, 1, 2, 20, 20, False, True),
+    (112, 32, 3, 1, 5, 20, 28, False, True), (256, 192, 3, 1, 1, 16, 16, False, True),
+    (384, 48, 1, 1, 1, 10, 10, False, False), (32, 32, 3, 1, 3, 17, 23, False, False),
+]
+
+
+@pytest.mark.parametrize("case", FP32_CONV_CASES, ids=lambda c: "f32_%d-%d_k%ds%dd%d_%dx%d" % c[:7])
+def test_conv_layer_fp32(nat, case):
+    cin, cout, k, s, dil, H, W, use_res, relu = case
+    g = torch.Generator().manual_seed(cin * 77 + cout + dil)
+    N = 2
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5
+    alpha = torch.rand(cout, generator=g) * 0.4 + 0.8
+    beta = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = H // s, W // s
+    res = torch.randn(N, cout, Ho, Wo, generator=g) if use_res else None
+    y = F.conv2d(x.double(), w.double(), None, s, dil * (k // 2), dil)
+    y = y * alpha.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)
+    if use_res:
+        y = y + res.double()
+    if relu:
+        y = F.relu(y)
+    dev = "cuda:0"
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    yd = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+    wn = w.contiguous().numpy()
+    a_np, b_np = alpha.contiguous().numpy(), beta.contiguous().numpy()
+    fp = ctypes.POINTER(ctypes.c_float)
+    nat.check(nat.lib().rtpe_conv2d_nhwc_ex(
+        xd.data_ptr(), N, H, W, cin, wn.ctypes.data, a_np.ctypes.data_as(fp), b_np.ctypes.data_as(fp),
+        cout, k, s, dil, (nat.F_RELU if relu else 0) | nat.F_F32, rd.data_ptr() if use_res else None,
+        yd.data_ptr(), nat.stream_ptr(torch.device(dev))))
+    got = yd.cpu().permute(0, 3, 1, 2).double()
+    err = (got - y).abs().max().item()
+    assert err <= 2e-5, "fp32 conv max error %.3e" % err           # fp32 FMA chains vs fp64
+
+
+def test_forward_fp32_vs_oracle_and_golden(nat, w48_shapes, golden_dir):
+    """configs[1]: the plain fp32 network (no half wrapper) on the GPU vs the CPU path"""
+    from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+    g = np.load(os.path.join(golden_dir, "hrnet_small.npz"))
+    for variant in ("W0", "W1"):
+        sd = synth.make_state_dict(w48_shapes, 0, variant)
+        net = PoseHigherResolutionNet()
+        net.load_state_dict(sd, strict=True)
+        net = net.to("cuda:0").eval()
+        x = synth.make_images(1, 128, 192)
+        with torch.no_grad():
+            preds, refined = net(x.to("cuda:0"))
+        assert preds.dtype == torch.float32 and preds.shape == (1, 34, 32, 48)
+        op, orf = hrnet_ref.hrnet_forward(sd, x, half=False)
+        for name, got, want, gold in (("preds", preds, op, g[variant + "_fp32_preds"]),
+                                      ("refined", refined, orf, g[variant + "_fp32_refined"])):
+            e1 = (got.cpu() - want).abs().max().item()
+            e2 = np.abs(got.cpu().numpy() - gold).max()
+            print("fp32 %s %s: max|d| vs oracle %.3e, vs golden %.3e" % (variant, name, e1, e2))
+            assert e1 <= 1e-3 and e2 <= 1e-3        # BASELINE.json: heatmap floats within 1e-3
+            assert e1 <= 2e-4                       # fp32 accumulation-order noise only
+
+
 # --------------------------------------------------------------------------- #
 # whole network
 # --------------------------------------------------------------------------- #
