@@ -68,6 +68,19 @@ int rtpe_device_count(void);
 #define RTPE_OP_FUSE 3   /* sum of up to 4 terms with nearest upsampling and a
                             final ReLU; HighResolutionModule.forward :245-254 */
 
+#define RTPE_OP_CAST 4        /* fp16 NHWC -> fp32 NHWC: tofp32 after the half-wrapped stem of
+                                 the students, fp16util.py:64-68, students.py:732-733 */
+#define RTPE_OP_AVGPOOL 5     /* AvgPool2d(3, 2, 1, count_include_pad=False), fp32,
+                                 students.py:657-666                            */
+#define RTPE_OP_SE 6          /* SELayer gate, students.py:118-142: cin = C, cout =
+                                 hidden; w_off -> fc1 w (hid,C), b1, fc2 w (C,hid),
+                                 b2 (fp32); output = per-image vector tensor    */
+#define RTPE_OP_CAM_COMBINE 7 /* relu(res + in * gate), ContextAwareModule
+                                 students.py:199-200; gate = term_t[0]          */
+#define RTPE_OP_SIGMOID_ADD 8 /* y = res + sigmoid(in[...,0] / 20) broadcast over
+                                 channels, students.py:755-756; the sigmoid map is
+                                 NCHW output 0 when RTPE_F_OUT_PREDS is set     */
+
 /* op flags */
 #define RTPE_F_RELU 1
 #define RTPE_F_ROUND_CONV 2 /* round the fp32 accumulator to fp16 before the
@@ -83,7 +96,8 @@ int rtpe_device_count(void);
 
 typedef struct rtpe_tensor_desc {
   int32_t channels; /* allocated channels per pixel (the NHWC row length)     */
-  int32_t ds_log2;  /* spatial size = (H >> ds_log2, W >> ds_log2)            */
+  int32_t ds_log2;  /* spatial size = (H >> ds_log2, W >> ds_log2); < 0: one
+                       vector of `channels` per image (SE gates)             */
   int32_t slot;     /* workspace slot (tensors with disjoint lifetimes share) */
   int32_t reserved; /* element size in bytes: 4 = fp32, anything else = fp16  */
 } rtpe_tensor_desc;
@@ -103,7 +117,10 @@ typedef struct rtpe_op_desc {
   int32_t term_t[4];       /* FUSE: term tensor ids                           */
   int32_t term_up[4];      /* FUSE: log2 nearest-upsampling factor per term   */
   int32_t reserved[3];     /* [0] logical Cin for cost accounting (0: = cin);
-                              [1] dilation of a 3x3 conv (0: 1)               */
+                              [1] dilation of a 3x3 conv (0: 1);
+                              [2] channels written to the NHWC output (0: all
+                              that fit; used to lay the HDC branches of a
+                              ContextAwareModule side by side)                */
 } rtpe_op_desc;
 
 typedef struct rtpe_hrnet rtpe_hrnet;

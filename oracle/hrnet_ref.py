@@ -143,14 +143,19 @@ class _Net:
                 xs.append(ys[i])
         return xs
 
-    def forward(self, x):
-        """PoseHigherResolutionNet.forward, pose_higher_hrnet.py:637-686"""
+    def stem(self, x):
+        """conv1..layer1 (pose_higher_hrnet.py:638-644; rtpe/students.py:242-255 StemHRNet.forward)"""
         if self.half:
             x = x.half()                                   # tofp16, fp16util.py:50-51
         x = F.relu(self.bn(self.conv(x, "conv1", 2, 1), "bn1"))
         x = F.relu(self.bn(self.conv(x, "conv2", 2, 1), "bn2"))
         for b in range(self.count("layer1.")):
             x = self.block(x, "layer1.%d." % b)
+        return x
+
+    def forward(self, x):
+        """PoseHigherResolutionNet.forward, pose_higher_hrnet.py:637-686"""
+        x = self.stem(x)
         ys = [x]
         for s in (2, 3, 4):
             n_new = self.count("stage%d.0.branches." % s)

@@ -38,6 +38,8 @@ def make_state_dict(shapes, seed=0, variant="W0", gain=1.0):
     sd = {}
     fan_in = {}
     for k, shp in shapes.items():
+        if k.endswith(".weight") and len(shp) == 2:       # Linear (out, in)
+            fan_in[k[:-7]] = shp[1]
         if k.endswith(".weight") and len(shp) == 4:
             # Conv2d: (Co, Ci, kh, kw) -> Ci*kh*kw.  ConvTranspose2d is
             # (Ci, Co, kh, kw); use the contraction length Ci*kh*kw/stride^2
@@ -50,7 +52,7 @@ def make_state_dict(shapes, seed=0, variant="W0", gain=1.0):
         g = _gen_for(seed, k)
         if k.endswith("num_batches_tracked"):
             sd[k] = torch.zeros((), dtype=torch.long)
-        elif k.endswith(".weight") and len(shp) == 4:
+        elif k.endswith(".weight") and len(shp) in (2, 4):
             b = gain / float(fan_in[k[:-7]]) ** 0.5
             sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * b
         elif k.endswith(".bias") and k[:-5] in fan_in:

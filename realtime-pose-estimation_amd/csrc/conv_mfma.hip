@@ -589,11 +589,16 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
   RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves, "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
+  // a launch shape belongs to one plan (halo = taps x dilation, pixel stride): never run a foreign one
+  RTPE_REQUIRE(t.kind == 1 || t.lds_bytes >= tile_lds(p, t.th, t.tw, t.waves, t.nt),
+               "conv tile (%zu B of LDS) was made for another plan (needs %zu B)", t.lds_bytes,
+               tile_lds(p, t.th, t.tw, t.waves, t.nt));
   RTPE_REQUIRE(a.kc * 4 * sizeof(int) <= (size_t)kTapTableBytes, "k chunk table overflow (kc=%d)", a.kc);
   const int eps = 16 / p.esize;
   RTPE_REQUIRE(a.in_ld % eps == 0 && (a.y == nullptr || (a.out_ld % eps == 0 && a.cout_store % eps == 0 &&
                                                          ((uintptr_t)a.y & 15) == 0)),
-               "conv: NHWC views must be 16-byte aligned with channel counts that are multiples of %d", eps);
+               "conv: NHWC views must be 16-byte aligned with channel counts that are multiples of %d "
+               "(in_ld=%d out_ld=%d cout_store=%d y=%p)", eps, a.in_ld, a.out_ld, a.cout_store, (void*)a.y);
   RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 1) return conv_persist_launch(p, t, a, s);

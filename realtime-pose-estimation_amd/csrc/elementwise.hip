@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
     }
     T o[EPS];
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) o[j] = (T)(acc[j] > 0.f ? acc[j] : 0.f);
+    for (int j = 0; j < EPS; ++j) o[j] = (T)((acc[j] > 0.f || !a.relu) ? acc[j] : 0.f);
     uint4 oraw;
     __builtin_memcpy(&oraw, o, 16);
     *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + (((size_t)n * a.H + y) * a.W + x) * a.out_ld + cs * EPS) = oraw;

@@ -119,6 +119,19 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
       if (d.cout != 64 || d.cin != 3) { set_error("stem must be 3->64"); delete h; return RTPE_E_INVALID; }
     } else if (d.kind == RTPE_OP_FUSE) {
       if (d.n_terms < 1 || d.n_terms > 4) { set_error("op %d: fuse terms", i); delete h; return RTPE_E_INVALID; }
+    } else if (d.kind == RTPE_OP_SE) {
+      const size_t wbytes = ((size_t)d.cout * d.cin * 2 + d.cout + d.cin) * 4;
+      if (d.w_off < 0 || (size_t)d.w_off + wbytes > weights_bytes) {
+        set_error("op %d: SE weights out of range", i); delete h; return RTPE_E_INVALID;
+      }
+      o.w_dev_off[0] = off;
+      off = align_up(off + wbytes, 256);
+    } else if (d.kind == RTPE_OP_CAST || d.kind == RTPE_OP_AVGPOOL || d.kind == RTPE_OP_CAM_COMBINE ||
+               d.kind == RTPE_OP_SIGMOID_ADD) {
+      if ((d.kind == RTPE_OP_CAM_COMBINE && (bad_t(d.res_t) || bad_t(d.term_t[0]))) ||
+          (d.kind == RTPE_OP_SIGMOID_ADD && bad_t(d.res_t))) {
+        set_error("op %d: missing operand tensor", i); delete h; return RTPE_E_INVALID;
+      }
     } else {
       set_error("op %d: unknown kind %d", i, d.kind); delete h; return RTPE_E_INVALID;
     }
@@ -148,6 +161,8 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
               memcpy(p + (size_t)(((ky * 3 + kx) * 3 + c) * 64 + co) * es,
                      w + (size_t)(((co * 3 + c) * 3 + ky) * 3 + kx) * es, es);
       memcpy(host.data() + o.ab_dev_off, wb + d.ab_off, 2 * 64 * sizeof(float));
+    } else if (d.kind == RTPE_OP_SE) {
+      memcpy(host.data() + o.w_dev_off[0], wb + d.w_off, ((size_t)d.cout * d.cin * 2 + d.cout + d.cin) * 4);
     }
   }
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->arena), off ? off : 256);
@@ -170,7 +185,8 @@ extern "C" int rtpe_hrnet_destroy(rtpe_hrnet* h) {
 static void slot_layout(const rtpe_hrnet* h, int N, int H, int W, std::vector<size_t>* offs, size_t* total) {
   std::vector<size_t> sz(h->n_slots, 0);
   for (const auto& t : h->tensors) {
-    const size_t b = (size_t)N * (H >> t.ds_log2) * (W >> t.ds_log2) * t.channels * (t.reserved == 4 ? 4 : 2);
+    const size_t px = t.ds_log2 < 0 ? 1 : (size_t)(H >> t.ds_log2) * (W >> t.ds_log2);
+    const size_t b = (size_t)N * px * t.channels * (t.reserved == 4 ? 4 : 2);
     if (b > sz[t.slot]) sz[t.slot] = b;
   }
   offs->resize(h->n_slots);
@@ -267,6 +283,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           int cs = o.plan[0].cout_pad;
           const int room = h->tensors[d.out_t].channels - d.out_coff;
           a.cout_store = cs < room ? cs : room;
+          if (d.reserved[2] > 0 && d.reserved[2] < a.cout_store) a.cout_store = d.reserved[2];
         }
         if (d.flags & RTPE_F_OUT_PREDS) { a.y_nchw = preds; a.nchw_channels = d.cout; }
         if (d.flags & RTPE_F_OUT_REFINED) { a.y_nchw = refined; a.nchw_channels = d.cout; }
@@ -293,6 +310,35 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
         rc = conv_launch(o.plan[k], tile, a, s);
       }
+    } else if (d.kind == RTPE_OP_CAST || d.kind == RTPE_OP_AVGPOOL || d.kind == RTPE_OP_SE ||
+               d.kind == RTPE_OP_CAM_COMBINE || d.kind == RTPE_OP_SIGMOID_ADD) {
+      const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+      const rtpe_tensor_desc& to = h->tensors[d.out_t];
+      const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
+      const size_t pixels = (size_t)N * Hi * Wi;
+      float* yo = reinterpret_cast<float*>(tptr(d.out_t, d.out_coff));
+      if (d.kind == RTPE_OP_CAST) {
+        rc = cast_launch(tptr(d.in_t, d.in_coff), ti.channels, yo, to.channels, d.cout, pixels, s);
+      } else if (d.kind == RTPE_OP_AVGPOOL) {
+        rc = avgpool_launch(reinterpret_cast<const float*>(tptr(d.in_t, d.in_coff)), ti.channels, yo, to.channels,
+                            d.cout, N, Hi, Wi, s);
+      } else if (d.kind == RTPE_OP_SE) {
+        rc = se_launch(reinterpret_cast<const float*>(tptr(d.in_t, d.in_coff)), ti.channels, d.cin, d.cout, N, Hi * Wi,
+                       reinterpret_cast<const float*>(h->arena + o.w_dev_off[0]), yo, to.channels, s);
+      } else if (d.kind == RTPE_OP_CAM_COMBINE) {
+        rc = cam_combine_launch(reinterpret_cast<const float*>(tptr(d.in_t, d.in_coff)), ti.channels,
+                                reinterpret_cast<const float*>(tptr(d.res_t, d.res_coff)), h->tensors[d.res_t].channels,
+                                reinterpret_cast<const float*>(tptr(d.term_t[0], 0)), h->tensors[d.term_t[0]].channels,
+                                yo, to.channels, d.cout, N, (size_t)Hi * Wi, s);
+      } else {
+        float* att_out = (d.flags & RTPE_F_OUT_PREDS) ? reinterpret_cast<float*>(preds) : nullptr;
+        if ((d.flags & RTPE_F_OUT_PREDS) && (!preds || out_dtype != RTPE_DTYPE_F32)) {
+          set_error("forward: the sigmoid map output must be a float32 buffer"); return RTPE_E_INVALID;
+        }
+        rc = sigmoid_add_launch(reinterpret_cast<const float*>(tptr(d.in_t, d.in_coff)), ti.channels,
+                                reinterpret_cast<const float*>(tptr(d.res_t, d.res_coff)), h->tensors[d.res_t].channels,
+                                yo, to.channels, d.cout, pixels, att_out, s);
+      }
     } else {  // FUSE
       const rtpe_tensor_desc& to = h->tensors[d.out_t];
       FuseArgs a;
@@ -307,6 +353,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.out_ld = to.channels; a.C = d.cout;
       a.N = N; a.H = H >> to.ds_log2; a.W = W >> to.ds_log2;
       a.f32 = (d.flags & RTPE_F_F32) ? 1 : 0;
+      a.relu = (d.flags & RTPE_F_RELU) ? 1 : 0;
       rc = fuse_launch(a, s);
     }
     if (rc != RTPE_OK) return rc;
@@ -350,6 +397,12 @@ extern "C" int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, in
     return RTPE_OK;
   }
   const int cin_logical = d.reserved[0] > 0 ? d.reserved[0] : d.cin;
+  if (d.kind >= RTPE_OP_CAST) {                      // small fp32 student ops: bytes only
+    const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+    const double px = (double)N * (H >> ti.ds_log2) * (W >> ti.ds_log2);
+    *bytes = px * ti.channels * 4 * 2;
+    return RTPE_OK;
+  }
   if (d.kind == RTPE_OP_STEM) {
     const double po = (double)N * (H / 2) * (W / 2);
     *flops = 2.0 * po * 64 * 27;
@@ -477,7 +530,7 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
   int rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
   if (rc != RTPE_OK) return rc;
 
-  typedef std::tuple<int, int, int, int, int, int, int, int> Key;
+  typedef std::tuple<int, int, int, int, int, int, int, int, int, int> Key;   // everything a launch shape depends on
   struct Class { std::vector<size_t> ops; std::vector<std::vector<ConvTile>> cands; std::vector<double> t; };
   std::map<Key, Class> classes;
   for (size_t i = 0; i < n_ops; ++i) {
@@ -486,7 +539,8 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
     if (o.n_geom == 0) continue;
     const rtpe_tensor_desc& ti = h->tensors[d.in_t];
     const Key key = std::make_tuple(d.cin, d.cout, d.ksize, d.stride, (int)d.kind, (int)ti.ds_log2, d.res_t >= 0 ? 1 : 0,
-                                    (int)(d.flags & (RTPE_F_OUT_PREDS | RTPE_F_OUT_REFINED | RTPE_F_NO_NHWC)));
+                                    (int)(d.flags & (RTPE_F_OUT_PREDS | RTPE_F_OUT_REFINED | RTPE_F_NO_NHWC | RTPE_F_F32)),
+                                    (int)d.reserved[1] /* dilation: sets the halo */, (int)d.reserved[2]);
     Class& c = classes[key];
     if (c.ops.empty()) {
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;

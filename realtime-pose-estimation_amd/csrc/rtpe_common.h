@@ -126,6 +126,7 @@ struct FuseArgs {
   int out_ld, C;
   int N, H, W;  // output spatial size
   int f32;      // 1: fp32 tensors (pointers are reinterpreted), 0: fp16
+  int relu;     // final ReLU (HighResolutionModule) or plain sum (student heads)
 };
 int fuse_launch(const FuseArgs& a, hipStream_t s);
 
@@ -140,5 +141,15 @@ struct StemArgs {
   int f32;      // 1: fp32 weights / output, no intermediate rounding
 };
 int stem_launch(const StemArgs& a, hipStream_t s);
+
+// ---- student ops (student_ops.hip), fp32 NHWC ------------------------------
+int cast_launch(const _Float16* x, int in_ld, float* y, int out_ld, int C, size_t pixels, hipStream_t s);
+int avgpool_launch(const float* x, int in_ld, float* y, int out_ld, int C, int N, int H, int W, hipStream_t s);
+int se_launch(const float* x, int in_ld, int C, int hid, int N, int HW, const float* w, float* gate, int gate_ld,
+              hipStream_t s);
+int cam_combine_launch(const float* hdc, int hdc_ld, const float* res, int res_ld, const float* gate, int gate_ld,
+                       float* y, int out_ld, int C, int N, size_t pix_per_image, hipStream_t s);
+int sigmoid_add_launch(const float* att, int att_ld, const float* x, int x_ld, float* y, int out_ld, int C,
+                       size_t pixels, float* att_out, hipStream_t s);
 
 }  // namespace rtpe

@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "librtpe_hip.so")
 
 RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
-OP_STEM, OP_CONV, OP_DECONV, OP_FUSE = 0, 1, 2, 3
+OP_STEM, OP_CONV, OP_DECONV, OP_FUSE, OP_CAST, OP_AVGPOOL, OP_SE, OP_CAM_COMBINE, OP_SIGMOID_ADD = range(9)
 F_RELU, F_ROUND_CONV, F_OUT_PREDS, F_OUT_REFINED, F_NO_NHWC, F_F32 = 1, 2, 4, 8, 16, 32
 
 

@@ -1,0 +1,222 @@
+"""The dual-head student of config 5 on MI355X.
+
+Drop-in for the parts of the reference's ``rtpe/students.py`` that
+``BASELINE.json`` configs[4] exercises: ``SELayer`` (:118-142),
+``ContextAwareModule`` (:145-201), ``StemHRNet`` (:206-283),
+``get_pretrained_stem`` (:286-298), ``init_weights`` (:20-32) and
+``AttentionStudent`` (:595-771) - same constructor signatures, same attribute
+names (hence the same state-dict keys: the bundled
+``assets/pretrained_segm_4MB/*.statedict`` load through ``load_state_dicts``),
+same ``forward(x, out_hw=None, return_intermediate=False) -> (att, det)``.
+The other student classes of that file are abandoned experiments (SURVEY.md
+section 2) and are not built.
+
+As for the teacher, the ``torch.nn`` leaves only hold parameters; ``forward``
+compiles the tree into one program (fp16 stem under the half wrapper, then a
+cast, then fp32 ops: dilated 3x3 convs on the exact-fp32 MFMA, SE gates, CAM
+combine, average pooling, sigmoid) and runs it on the HIP executor.  The quirks
+of the reference forward are reproduced as they are: ``att = hi + 2*up(lo)``
+(:739-742), ``det_hi`` used for both ``hi`` and ``mid`` and ``det_mid`` never
+called (:759-760).
+"""
+import torch
+
+from . import _native as nat
+from .third_party.fp16_utils.fp16util import network_to_half, tofp16
+from .third_party.pose_higher_hrnet import BN_MOMENTUM, Bottleneck, Engine, ProgramBuilder
+
+
+def init_weights(module, init_fn=torch.nn.init.kaiming_normal_, bias_val=0.0):
+    """reference :20-32"""
+    if isinstance(module, (torch.nn.Linear, torch.nn.Conv2d)):
+        init_fn(module.weight)
+        if module.bias is not None:
+            module.bias.data.fill_(bias_val)
+
+
+class SELayer(torch.nn.Module):
+    """squeeze-excitation gate (reference :118-142): returns the (N,C,1,1) gate only"""
+
+    def __init__(self, in_chans, hidden_chans=None, bn_momentum=0.1):
+        super().__init__()
+        hidden_chans = in_chans // 4 if hidden_chans is None else hidden_chans
+        self.avg_pool = torch.nn.AdaptiveAvgPool2d(1)
+        self.fc = torch.nn.Sequential(torch.nn.Linear(in_chans, hidden_chans, bias=True),
+                                      torch.nn.ReLU(inplace=True),
+                                      torch.nn.Linear(hidden_chans, in_chans, bias=True),
+                                      torch.nn.Sigmoid())
+
+    def emit(self, b, x):
+        return b.se(x, self.fc[0], self.fc[2])
+
+    def forward(self, x):
+        raise RuntimeError("rtpe: SELayer runs only inside a compiled student program")
+
+
+def _cbr(cin, cout, k, dilation=1, bn_momentum=0.1):
+    return torch.nn.Sequential(
+        torch.nn.Conv2d(cin, cout, kernel_size=k, stride=1, dilation=dilation,
+                        padding=dilation * (k // 2), bias=False),
+        torch.nn.BatchNorm2d(cout, momentum=bn_momentum), torch.nn.ReLU(inplace=True))
+
+
+class ContextAwareModule(torch.nn.Module):
+    """CAM (reference :145-201): relu(residual(x) + hdc_top(cat(hdc_d(x))) * se(x))"""
+
+    def __init__(self, in_chans, se_chans=None, hdc_dilations=[1, 2, 3, 4], hdc_chans=None, bn_momentum=0.1):
+        super().__init__()
+        self.residual = _cbr(in_chans, in_chans, 1, bn_momentum=bn_momentum)
+        self.se = SELayer(in_chans, se_chans, bn_momentum)
+        hdc_chans = in_chans // 4 if hdc_chans is None else hdc_chans
+        self.hdcs = torch.nn.ModuleList([_cbr(in_chans, hdc_chans, 3, d, bn_momentum) for d in hdc_dilations])
+        self.hdc_top = _cbr(hdc_chans * len(hdc_dilations), in_chans, 1, bn_momentum=bn_momentum)
+        self.final_relu = torch.nn.ReLU(inplace=True)
+
+    def emit(self, b, x):
+        res = b.conv(x, self.residual[0], self.residual[1], relu=True)
+        gate = self.se.emit(b, x)
+        # torch.cat of the dilated branches (:191) without a copy: every branch writes its
+        # channels side by side; each slice is padded to a multiple of 4 channels (16 bytes)
+        hc = self.hdcs[0][0].out_channels
+        hp = (hc + 3) // 4 * 4
+        nd = len(self.hdcs)
+        cat = b.new_tensor(hp * nd, b.tensors[x][1])
+        for i, hdc in enumerate(self.hdcs):
+            b.conv(x, hdc[0], hdc[1], relu=True, out=(cat, hp * i), cout_store=hp)
+        w = self.hdc_top[0].weight.detach().cpu()                      # (C, hc*nd, 1, 1)
+        wp = torch.zeros((w.shape[0], hp * nd, 1, 1), dtype=w.dtype)
+        for i in range(nd):
+            wp[:, hp * i:hp * i + hc] = w[:, hc * i:hc * (i + 1)]
+        top = b.conv(cat, self.hdc_top[0], self.hdc_top[1], relu=True, weight=wp, cin=hp * nd)
+        return b.cam_combine(top, res, gate)
+
+    def forward(self, x):
+        raise RuntimeError("rtpe: ContextAwareModule runs only inside a compiled student program")
+
+
+class StemHRNet(torch.nn.Module):
+    """stem + layer1 of HigherHRNet (reference :206-283); same keys as the teacher's stem"""
+    INPLANES = 64
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(3, self.INPLANES, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn1 = torch.nn.BatchNorm2d(self.INPLANES, momentum=BN_MOMENTUM)
+        self.conv2 = torch.nn.Conv2d(self.INPLANES, self.INPLANES, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn2 = torch.nn.BatchNorm2d(self.INPLANES, momentum=BN_MOMENTUM)
+        self.relu = torch.nn.ReLU(inplace=True)
+        proj = torch.nn.Sequential(torch.nn.Conv2d(64, 256, kernel_size=1, stride=1, bias=False),
+                                   torch.nn.BatchNorm2d(256, momentum=BN_MOMENTUM))
+        self.layer1 = torch.nn.Sequential(Bottleneck(64, 64, 1, proj), *[Bottleneck(256, 64) for _ in range(3)])
+
+    def emit(self, b):
+        t = b.stem(self.conv1, self.bn1)
+        t = b.conv(t, self.conv2, self.bn2, relu=True)
+        for blk in self.layer1:
+            t = blk.emit(b, t)
+        return t
+
+    def load_pretrained(self, hhrnet_statedict_path, device="cpu", check=False):
+        """reference :262-283: picks the stem keys (``1.`` + key) out of the teacher checkpoint"""
+        hhrnet_d = torch.load(hhrnet_statedict_path, map_location=device)
+        self.load_state_dict({k: hhrnet_d["1." + k] for k in self.state_dict()})
+        if check:
+            assert all((hhrnet_d["1." + k].to(device) == v.to(device)).all() for k, v in self.state_dict().items())
+
+    def forward(self, x):
+        raise RuntimeError("rtpe: StemHRNet runs only inside a compiled student program")
+
+
+def get_pretrained_stem(hhrnet_statedict_path, device="cuda", half_precision=True):
+    """reference :286-298"""
+    stem = network_to_half(StemHRNet()) if half_precision else \
+        torch.nn.Sequential(torch.nn.Identity(), StemHRNet())
+    stem[1].load_pretrained(hhrnet_statedict_path, device, check=False)
+    return stem
+
+
+class AttentionStudent(torch.nn.Module):
+    """reference :595-771"""
+
+    def __init__(self, hhrnet_statedict_path=None, device="cuda", inplanes=48, num_heatmaps=17, ae_dims=1,
+                 half_precision=True, init_fn=torch.nn.init.kaiming_normal_, trainable_stem=False,
+                 bn_momentum=0.1):
+        super().__init__()
+        self.bn_momentum = bn_momentum
+        self.num_heatmaps, self.ae_dims = num_heatmaps, ae_dims
+        self.stem = StemHRNet()
+        self.stem_out_chans = self.stem.layer1[-1].bn3.num_features
+        self.trainable_stem = trainable_stem
+        self.inplanes = inplanes
+        mid = (self.stem_out_chans + inplanes) // 2
+        m1, m2 = _cbr(self.stem_out_chans, mid, 3, bn_momentum=bn_momentum), _cbr(mid, inplanes, 3, bn_momentum=bn_momentum)
+        self.mid_stem = torch.nn.Sequential(*m1, *m2)
+        self.att_lo, self.att_mid, self.att_hi, self.att_top = self._body([1, 2, 3, 4, 5], 1)
+        self.det_lo, self.det_mid, self.det_hi, self.det_top = self._body([1, 2, 3, 4], num_heatmaps + ae_dims)
+        if init_fn is not None:
+            self.apply(lambda module: init_weights(module, init_fn, 0.0))
+        self.stem = network_to_half(self.stem) if half_precision else \
+            torch.nn.Sequential(torch.nn.Identity(), self.stem)
+        if hhrnet_statedict_path is not None:
+            self.stem[1].load_pretrained(hhrnet_statedict_path, device, check=False)
+        self._engines = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m._engines.clear())
+        self.to(device)
+        self.device = device
+
+    def _body(self, dilations, top_chans):
+        """reference :651-706: [AvgPool+CAM, AvgPool+CAM, CAM, 3x3 conv with bias]"""
+        pool = lambda: torch.nn.AvgPool2d(kernel_size=3, stride=2, padding=1, count_include_pad=False)
+        cam = lambda: ContextAwareModule(self.inplanes, hdc_dilations=dilations)
+        top = torch.nn.Sequential(torch.nn.Conv2d(self.inplanes, top_chans, kernel_size=3, stride=1,
+                                                  dilation=1, padding=1, bias=True))
+        return torch.nn.ModuleList([torch.nn.Sequential(pool(), cam()), torch.nn.Sequential(pool(), cam()),
+                                    torch.nn.Sequential(cam()), top])
+
+    def load_state_dicts(self, inpath):
+        """reference :708-722"""
+        for name in ("mid_stem", "att_lo", "att_mid", "att_hi", "att_top"):
+            getattr(self, name).load_state_dict(torch.load(inpath + name + ".statedict", map_location="cpu"))
+        self._engines.clear()
+
+    def _apply(self, fn, *a, **kw):
+        self._engines.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def compile_program(self):
+        """the forward of reference :724-771 as one program"""
+        half = isinstance(self.stem[0], tofp16)
+        b = ProgramBuilder(f32=not half)
+        t = self.stem[1].emit(b)
+        if half:
+            t = b.cast(t)                                   # tofp32 of the wrapped stem
+        b.f32 = True
+        m = self.mid_stem
+        t = b.conv(t, m[0], m[1], relu=True)
+        stem_out = b.conv(t, m[3], m[4], relu=True)
+        # human-mask (attention) head: hi + up(lo) + up(lo), :736-744
+        hi = self.att_hi[0].emit(b, stem_out)
+        mid = self.att_mid[1].emit(b, b.avgpool(stem_out))
+        lo = self.att_lo[1].emit(b, b.avgpool(mid))
+        att = b.fuse([(hi, 0), (lo, 2), (lo, 2)], relu=False)
+        logits = b.conv(att, self.att_top[0], None)
+        stem_out = b.sigmoid_add(logits, stem_out, out_flag=nat.F_OUT_PREDS)     # :755-756
+        # keypoint head: det_hi for hi AND mid, det_lo on top of it, :759-769
+        hi = self.det_hi[0].emit(b, stem_out)
+        lo = self.det_lo[1].emit(b, b.avgpool(hi))
+        det = b.fuse([(hi, 0), (lo, 1), (lo, 1)], relu=False)
+        b.conv(det, self.det_top[0], None, out_flag=nat.F_OUT_REFINED, nhwc=False)
+        return b.finish()
+
+    def forward(self, x, out_hw=None, return_intermediate=False):
+        """x (N,3,H,W) fp32 on the GPU, H and W multiples of 32 -> (att (N,1,H/4,W/4) = sigmoid mask,
+        det (N,num_heatmaps+ae_dims,H/4,W/4)), both fp32.  ``out_hw`` and
+        ``return_intermediate`` are accepted and unused, as in the reference."""
+        nat.require_gpu(x, "AttentionStudent.forward")
+        key = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = Engine(self.compile_program(), key)
+            self._engines[key] = eng
+        att, det = eng.forward(x.float(), torch.float32)
+        return att, det

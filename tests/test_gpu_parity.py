@@ -393,3 +393,37 @@ def test_end_to_end_pipeline_and_margin_aware_indices(nat, teacher):
             assert tuple(got_tk["loc_k"][0, j, 0]) == tuple(ref_tk["loc_k"][0, j, 0])
             checked += 1
     print("margin-aware arg-max agreement checked on %d joints" % checked)
+
+
+# --------------------------------------------------------------------------- #
+# config 5: the dual-head student
+# --------------------------------------------------------------------------- #
+def test_student_vs_golden_and_oracle(nat, golden_dir):
+    """AttentionStudent(inplanes=100) (students.py:595-771): half-wrapped stem + fp32 heads on the GPU
+    vs the reference's CPU output (fixture) and the oracle restatement at a second, non-square size.
+    Tolerance: BASELINE.json's 1e-3 on the outputs (att is a sigmoid in [0,1]; det logits are O(1))."""
+    import json
+    from oracle import student_ref
+    from rtpe.students import AttentionStudent
+    shapes = json.load(open(os.path.join(golden_dir, "student_shapes.json")))["shapes"]
+    sd = synth.make_state_dict({k: tuple(v) for k, v in shapes.items()}, 3, "W1")
+    stu = AttentionStudent(None, "cpu", 100, 17, 1, True, None, False).eval()
+    stu.load_state_dict(sd, strict=True)
+    stu = stu.to("cuda:0")
+    g = np.load(os.path.join(golden_dir, "student.npz"))
+    x = synth.make_images(2, 320, 320, seed=99)
+    with torch.no_grad():
+        att, det = stu(x.to("cuda:0"))
+    assert att.shape == (2, 1, 80, 80) and det.shape == (2, 18, 80, 80) and att.dtype == torch.float32
+    ea = np.abs(att.cpu().numpy() - g["att"]).max()
+    ed = np.abs(det.cpu().numpy() - g["det"]).max()
+    print("student vs golden: att %.3e det %.3e (det range %.2f)" % (ea, ed, np.abs(g["det"]).max()))
+    assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, np.abs(g["det"]).max())
+    x2 = synth.make_images(1, 192, 256, seed=5)
+    oa, od = student_ref.student_forward(sd, x2, half_stem=True)
+    with torch.no_grad():
+        att2, det2 = stu(x2.to("cuda:0"))
+    ea = (att2.cpu() - oa).abs().max().item()
+    ed = (det2.cpu() - od).abs().max().item()
+    print("student vs oracle 192x256: att %.3e det %.3e" % (ea, ed))
+    assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())

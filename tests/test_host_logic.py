@@ -1,6 +1,7 @@
 """CPU-side tests of the product: state-dict contract, program compiler, C-ABI
 exports, the host matcher (C++), sharding / record packing, and the N>1 path
 over gloo.  No GPU, no compute kernels."""
+import json
 import os
 import re
 
@@ -185,3 +186,31 @@ def test_two_rank_gather_and_weight_broadcast_gloo():
     for rank, keys, vals, a, b, n in got:
         assert keys == [0, 1, 2, 3, 4] and vals == [0., 1., 2., 3., 4.]
         assert a == [[0., 1., 2.], [3., 4., 5.]] and b == [3.] * 4 and n == 5
+
+
+def test_student_state_dict_and_program(built, golden_dir):
+    """config 5: AttentionStudent keeps the reference's parameter names/shapes (students.py:595-722,
+    incl. the per-submodule ``load_state_dicts`` files) and compiles to one program"""
+    from rtpe.students import AttentionStudent
+    shapes = json.load(open(os.path.join(golden_dir, "student_shapes.json")))["shapes"]
+    stu = AttentionStudent(None, "cpu", 100, 17, 1, True, None, False).eval()
+    assert {k: list(v.shape) for k, v in stu.state_dict().items()} == shapes
+    sd = synth.make_state_dict({k: tuple(v) for k, v in shapes.items()}, 3, "W1")
+    stu.load_state_dict(sd, strict=True)
+    assert stu.stem[1].conv1.weight.dtype == torch.float16          # half-wrapped stem
+    assert stu.stem[1].bn1.weight.dtype == torch.float32 and stu.mid_stem[0].weight.dtype == torch.float32
+    prog = stu.compile_program()
+    kinds = [op.kind for op in prog.ops]
+    assert kinds.count(built.OP_STEM) == 1 and kinds.count(built.OP_CAST) == 1
+    assert kinds.count(built.OP_SE) == 5 and kinds.count(built.OP_CAM_COMBINE) == 5      # det_mid is never run
+    assert kinds.count(built.OP_AVGPOOL) == 3 and kinds.count(built.OP_SIGMOID_ADD) == 1
+    assert prog.n_preds == 1 and prog.n_refined == 18 and prog.outputs == [(1, 2), (18, 2)]
+    # per-submodule files round-trip through load_state_dicts
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        pre = os.path.join(d, "x_")
+        for name in ("mid_stem", "att_lo", "att_mid", "att_hi", "att_top"):
+            torch.save({k: v + 1 for k, v in getattr(stu, name).state_dict().items()}, pre + name + ".statedict")
+        before = stu.att_top[0].bias.clone()
+        stu.load_state_dicts(pre)
+        assert torch.equal(stu.att_top[0].bias, before + 1)

@@ -169,5 +169,33 @@ def main():
         print(name, "people found", len(ans[0]))
 
 
+    # ---- config 5: AttentionStudent(inplanes=100), students.py:595-771 ---------------
+    from rtpe.students import AttentionStudent
+    from oracle import student_ref
+    torch.manual_seed(0)
+    stu = AttentionStudent(None, "cpu", 100, 17, 1, True, None, False).eval()
+    st_shapes = {k: list(v.shape) for k, v in stu.state_dict().items()}
+    with open(os.path.join(OUT, "student_shapes.json"), "w") as f:
+        json.dump({"n_keys": len(st_shapes), "shapes": st_shapes}, f)
+    ssd = synth.make_state_dict({k: tuple(v) for k, v in st_shapes.items()}, 3, "W1")
+    stu.load_state_dict(ssd, strict=True)          # stem conv weights are rounded to fp16 by the copy
+    xs = synth.make_images(2, 320, 320, seed=99)
+    with torch.no_grad():
+        att, det = stu(xs)
+    oa, od = student_ref.student_forward(ssd, xs, half_stem=True)
+    print("student synthetic: oracle vs reference max diff", float((oa - att).abs().max()), float((od - det).abs().max()))
+    # the bundled trained attention weights (assets/pretrained_segm_4MB) validate the restatement too
+    import glob
+    pre = glob.glob(os.path.join(REF, "assets", "pretrained_segm_4MB", "*mid_stem.statedict"))[0][:-len("mid_stem.statedict")]
+    stu.load_state_dicts(pre)
+    with torch.no_grad():
+        att_b, det_b = stu(xs)
+    ob_a, ob_d = student_ref.student_forward(stu.state_dict(), xs, half_stem=True)
+    d_b = (float((ob_a - att_b).abs().max()), float((ob_d - det_b).abs().max()))
+    print("student bundled weights: oracle vs reference max diff", d_b)
+    np.savez_compressed(os.path.join(OUT, "student.npz"), att=att.numpy(), det=det.numpy(),
+                        bundled_oracle_vs_reference_maxdiff=np.array(d_b))
+
+
 if __name__ == "__main__":
     main()
