@@ -464,7 +464,64 @@ static ConvTile make_persist_tile(const ConvPlan& p, int N, int H_pos, int W_pos
   return best;
 }
 
+// streaming kernel (conv_stream.hip): one workgroup per CU, 3-slot weight ring + 2-3 halo buffers
+static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, ConvTile* out) {
+  if (!conv_stream_supports(p) || (c.nt != 4 && c.nt != 5) || c.tw > 40) return false;
+  const int hh = c.th + 2, hw = c.tw + 2;
+  const size_t in_tile = (size_t)hh * hw * p.pstride;
+  const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
+  size_t buf = in_tile > out_tile ? in_tile : out_tile;
+  buf = (buf + 255) / 256 * 256;
+  // weights resident (loaded once per workgroup) when all halves of a cout block fit beside 2 halo buffers
+  int nw = 3, nb = 3;
+  if (p.n_cchunks <= 2 && conv_stream_lds(p, (int)buf, 2, 2 * p.n_cchunks) <= 160 * 1024) nw = 2 * p.n_cchunks;
+  if (conv_stream_lds(p, (int)buf, nb, nw) > 160 * 1024) nb = 2;
+  if (conv_stream_lds(p, (int)buf, nb, nw) > 160 * 1024) return false;
+  const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
+  const long units = tiles * p.n_cb;
+  long G = 32;                                            // one workgroup per CU
+  const long need = (units + 7) / 8;
+  if (G > need) G = need;
+  G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
+  memset(out, 0, sizeof(*out));
+  out->nt = c.nt; out->waves = c.waves; out->th = c.th; out->tw = c.tw;
+  out->kind = 2; out->grid = (int)(8 * G); out->buf_bytes = (int)buf; out->n_bufs = nb;
+  out->n_wslots = nw;
+  out->lds_bytes = conv_stream_lds(p, (int)buf, nb, nw);
+  return true;
+}
+
+static ConvTile make_stream_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+  static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
+  static const int force_waves = getenv("RTPE_CONV_WAVES") ? atoi(getenv("RTPE_CONV_WAVES")) : 0;
+  static const int force_th = getenv("RTPE_CONV_TH") ? atoi(getenv("RTPE_CONV_TH")) : 0;
+  double best_score = 1e30;
+  ConvTile best;
+  memset(&best, 0, sizeof(best));
+  for (const TileCand& c : kCands) {
+    ConvTile t;
+    if ((force_nt && c.nt != force_nt) || (force_waves && c.waves != force_waves) || (force_th && c.th != force_th)) continue;
+    if (!stream_tile(p, c, N, H_pos, W_pos, &t)) continue;
+    const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
+                         ((double)H_pos * W_pos);
+    const long units = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N * p.n_cb;
+    const double rounds = (double)units / t.grid;
+    const double imbalance = rounds >= 1.0 ? (double)((long)(rounds + 0.999)) / rounds : 1.0;
+    const double halo = (double)(c.th + 2) * (c.tw + 2) / ((double)c.th * c.tw);
+    // 5 MFMA waves leave one SIMD with two of them; resident weights save the per-stage weight stream
+    const double score = waste * imbalance * (1.0 + 0.15 * (halo - 1.0)) * (t.n_bufs == 3 ? 1.0 : 1.05) *
+                         (c.waves == 5 ? 1.3 : 1.0) * (t.n_wslots == 3 ? 1.0 : 0.8);
+    if (score < best_score) { best_score = score; best = t; }
+  }
+  return best;
+}
+
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+  static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
+  if (stream && conv_stream_supports(p)) {
+    ConvTile t = make_stream_tile(p, N, H_pos, W_pos);
+    if (t.nt) return t;
+  }
   static const int persist = getenv("RTPE_CONV_PERSIST") ? atoi(getenv("RTPE_CONV_PERSIST")) : 1;
   if (persist && p.esize == 2 && p.dil == 1 && p.cc == 48 && p.pstride == 96) {
     ConvTile t = make_persist_tile(p, N, H_pos, W_pos);
@@ -521,6 +578,8 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
   a->n_cb = p.n_cb;
   a->buf_bytes = t.buf_bytes;
+  a->n_bufs = t.n_bufs;
+  a->n_wslots = t.n_wslots;
   // ablation for profiling only: RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
   static const int skipk = getenv("RTPE_CONV_SKIPK") ? atoi(getenv("RTPE_CONV_SKIPK")) : 0;
   if (skipk) a->kc = 0;
@@ -564,6 +623,10 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     t.nt = c.nt; t.waves = c.waves; t.th = c.th; t.tw = c.tw;
     t.lds_bytes = tile_lds(p, c.th, c.tw, c.waves, c.nt);
     if (t.lds_bytes <= 160 * 1024) out->push_back(t);              // one workgroup per tile
+    {
+      ConvTile st;
+      if (stream_tile(p, c, N, H_pos, W_pos, &st)) out->push_back(st);   // streaming, LDS-DMA operands
+    }
     if (p.esize == 2 && p.dil == 1 && p.cc == 48 && p.pstride == 96 && c.nt <= 5) {   // persistent + loader wave
       size_t buf = in_tile > out_tile ? in_tile : out_tile;
       buf = (buf + 1023) / 1024 * 1024;
@@ -590,7 +653,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves, "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
   // a launch shape belongs to one plan (halo = taps x dilation, pixel stride): never run a foreign one
-  RTPE_REQUIRE(t.kind == 1 || t.lds_bytes >= tile_lds(p, t.th, t.tw, t.waves, t.nt),
+  RTPE_REQUIRE(t.kind != 0 || t.lds_bytes >= tile_lds(p, t.th, t.tw, t.waves, t.nt),
                "conv tile (%zu B of LDS) was made for another plan (needs %zu B)", t.lds_bytes,
                tile_lds(p, t.th, t.tw, t.waves, t.nt));
   RTPE_REQUIRE(a.kc * 4 * sizeof(int) <= (size_t)kTapTableBytes, "k chunk table overflow (kc=%d)", a.kc);
@@ -602,6 +665,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 1) return conv_persist_launch(p, t, a, s);
+  if (t.kind == 2) return conv_stream_launch(p, t, a, s);
 #define RTPE_V(MTv, NTv, Wv)                                                                  \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv)                                            \
     return p.esize == 4 ? launch_variant<float, MTv, NTv, Wv>(t, a, p.n_cb, s)                 \

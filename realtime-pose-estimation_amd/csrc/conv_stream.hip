@@ -1,0 +1,536 @@
+// Streaming implicit-GEMM 3x3 convolution for the 48-channel-chunked layers of the
+// w48 network (Cin in {48, 96, 192, 384}, stride 1: every BasicBlock conv, i.e. ~85 %
+// of the forward FLOPs; pose_higher_hrnet.py:46-75 of the reference).  Same math, same
+// k order, same epilogue rounding points and the same packed-weight format as
+// conv_mfma.hip, so results are bit-identical; what changes is how operands reach the
+// MFMAs.  Measured on the one-workgroup-per-tile kernel: every layer class sat at
+// 450-500 TFLOP/s whatever its shape, because (i) each wave fetched its weight
+// fragments from L1/L2 (4 waves x 3 KiB per k-step = the whole 64 B/clk of a CU's
+// vector cache at MFMA rate), (ii) staging and k-loop of a workgroup were serial.
+//
+//   * ONE persistent workgroup per CU: WAVES MFMA waves + 3 loader waves, walking an
+//     XCD-aware list of (tile, cout block) units;
+//   * loader waves move bytes with LDS-DMA (`buffer_load ... lds`, 1 KiB per
+//     instruction, no VGPRs):  one streams the WEIGHT fragments of the next half
+//     stage (7 k-steps, MT x 7 KiB) into a 3-slot LDS ring, so all MFMA waves share
+//     one copy through LDS instead of 4-5 copies through L1; two alternate on the
+//     input HALO tiles (up to 3 LDS buffers: tile s+2 is requested while s is being
+//     multiplied).  Halo rows are issued row by row: the per-lane column offsets are
+//     computed once per tile, the row base is a scalar, so a DMA instruction costs no
+//     VALU work.  Out-of-image pixels use an out-of-range buffer offset: the bounds
+//     check returns zeros (= the conv padding);
+//   * each loader owns its own vmcnt stream, so every wait is a constant
+//     `s_waitcnt vmcnt(N)`; hand-over is by workgroup barriers (M: stage start,
+//     H: mid-stage, E: before the epilogue reuses the tile buffer);
+//   * MFMA waves: k-loop fully unrolled per half stage, A (weights) and B (pixels)
+//     fragments both read from LDS one k-step ahead of the MFMAs that use them.
+#include <type_traits>
+
+#include "rtpe_common.h"
+
+namespace rtpe {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef short short8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int kCC = 48;          // channels per staged chunk
+constexpr int kSlots = 6;        // 16-byte slots per staged pixel
+constexpr int kPStride = 96;     // LDS bytes per staged pixel
+constexpr int kKC = 14;          // k-steps per stage (9 taps x 48 channels, padded to 448)
+constexpr int kKH = 7;           // k-steps per half stage
+constexpr int kLoaders = 3;
+
+__device__ __forceinline__ float round16s(float v) { return (float)(_Float16)v; }
+
+#define RTPE_SBARRIER()                         \
+  do {                                          \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+  } while (0)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#ifdef RTPE_CONV_STAMPS
+#define SSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SSTAMP(v)
+#endif
+
+// XCD x (= blockIdx % 8) owns tiles x, x+8, ...; its G workgroups walk that XCD's
+// (tile, cout block) sequence with stride G (G % n_cb == 0: a workgroup keeps its
+// cout block, and the cout blocks of a tile share its halo through that XCD's L2).
+struct Units {
+  int n_tiles, n_cb, G, xcd, j, count;
+  __device__ __forceinline__ void init(int n_tiles_, int n_cb_) {
+    n_tiles = n_tiles_; n_cb = n_cb_;
+    G = (int)(gridDim.x >> 3);
+    xcd = (int)(blockIdx.x & 7);
+    j = (int)(blockIdx.x >> 3);
+    const int tiles_xcd = (n_tiles - xcd + 7) >> 3;
+    const int n_seq = tiles_xcd * n_cb;
+    count = j < n_seq ? (n_seq - j + G - 1) / G : 0;
+  }
+  __device__ __forceinline__ void get(int i, int* tile, int* cb) const {
+    const int seq = j + i * G;
+    const int tq = seq / n_cb;
+    *cb = seq - tq * n_cb;
+    *tile = xcd + 8 * tq;
+  }
+};
+
+}  // namespace
+
+template <int MT, int NT, int WAVES>
+__global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WSLOT = MT * kKH * 1024;               // weight fragments of one half stage
+  char* const wring = smem;
+  const int NWS = a.n_wslots;                           // weight half-stage slots in LDS
+  char* const tiles = smem + NWS * WSLOT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  Units um;
+  um.init(a.N * a.tiles_x * a.tiles_y, a.n_cb);
+  const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
+  const int ncc = a.n_cchunks;                          // power of two (host-checked)
+  const int sh = __builtin_ctz((unsigned)ncc);
+  const int S = um.count << sh;                         // stages of this workgroup
+  const int NB = a.n_bufs;                              // halo tile buffers (2 or 3)
+  // a workgroup keeps its cout block: when all 2*ncc weight halves of it fit, they are loaded once
+  const bool resident = NWS == 2 * ncc;
+  if (S == 0) return;
+
+  if (wv == WAVES) {
+    // ----------------------------- weight loader -----------------------------
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(a.w), 0, a.n_cb * ncc * kKC * MT * 1024, 0x00020000);
+    const int voff = lane * 16;
+    auto issue = [&](int q) {                            // half stage q = 2 s + h
+      const int s = q >> 1, h = q & 1;
+      int tile, cb;
+      um.get(s >> sh, &tile, &cb);
+      const int cci = s & (ncc - 1);
+      const int src = ((cb * ncc + cci) * kKC + h * kKH) * MT * 1024;
+      char* dst = wring + (resident ? q : q % 3) * WSLOT;
+#pragma unroll
+      for (int p = 0; p < MT * kKH; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + p * 1024), 16, voff, src + p * 1024, 0, 0);
+    };
+#ifdef RTPE_CONV_STAMPS
+    unsigned long long w0, w1, w2, w3, w4, wwait = 0, wissue = 0;
+#endif
+    if (resident) {
+      for (int q = 0; q < 2 * ncc; ++q) issue(q);        // stages 0..ncc-1 of unit 0 = every (cci, half)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int s = 0; s < S; ++s) {
+        RTPE_SBARRIER();                                 // M(s)
+        if ((s & (ncc - 1)) == ncc - 1) RTPE_SBARRIER(); // E(s)
+      }
+      return;
+    }
+    const int Q = 2 * S;
+    issue(0);
+    issue(1);
+    for (int s = 0; s < S; ++s) {
+      SSTAMP(w0);
+      // everything but the most recent half (MT*7 instructions) has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * kKH) : "memory");
+      SSTAMP(w1);
+      RTPE_SBARRIER();                                   // M(s)
+      SSTAMP(w2);
+      const bool more0 = 2 * s + 2 < Q;
+      if (more0) issue(2 * s + 2);
+      SSTAMP(w3);
+      if (more0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * kKH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SSTAMP(w4);
+      RTPE_SBARRIER();                                   // H(s)
+      if (2 * s + 3 < Q) issue(2 * s + 3);
+      if ((s & (ncc - 1)) == ncc - 1) RTPE_SBARRIER();   // E(s)
+#ifdef RTPE_CONV_STAMPS
+      wwait += (w1 - w0) + (w4 - w3); wissue += w3 - w2;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RTPE_CONV_STAMPS
+    if (a.dbg != nullptr && lane == 0) { atomicAdd(&a.dbg[6], wwait); atomicAdd(&a.dbg[7], wissue); atomicAdd(&a.dbg[11], (unsigned long long)S); }
+#endif
+    return;
+  }
+
+  if (wv > WAVES) {
+    // ------------------------------ tile loaders ------------------------------
+    const int jl = wv - WAVES - 1;                       // 0 or 1
+    const int NTL = NB - 1;                              // active tile loaders
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const int rowslots = a.halo_w * kSlots;
+    const int rowbytes = a.halo_w * kPStride;
+    auto issue = [&](int s, int r0, int r1) {           // halo rows [r0, r1) of the tile of stage s
+      int tile, cb;
+      um.get(s >> sh, &tile, &cb);
+      const int cbase = (s & (ncc - 1)) * kCC;
+      uint32_t t = (uint32_t)tile;
+      const uint32_t n = fdiv(t, a.div_tiles_xy);
+      t -= n * tiles_xy;
+      const uint32_t tyi = fdiv(t, a.div_tiles_x);
+      const uint32_t txi = t - tyi * a.tiles_x;
+      const int iy0 = (int)tyi * a.th + a.lo_y, ix0 = (int)txi * a.tw + a.lo_x;
+      // per-lane column part of the address, one value per DMA instruction of a row
+      uint32_t voff[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = k * 64 + lane;
+        const int hx = q / kSlots, sl = q - hx * kSlots;
+        const int ix = ix0 + hx;
+        const bool ok = (unsigned)ix < (unsigned)a.W_in && cbase + sl * 8 < a.cin;
+        voff[k] = ok ? (uint32_t)(ix * a.in_ld + cbase + sl * 8) * 2u : 0x80000000u;
+      }
+      char* buf = tiles + (s % NB) * a.buf_bytes;
+      const int img_row0 = (int)n * a.H_in;
+      for (int r = r0; r < r1; ++r) {
+        const int iy = iy0 + r;
+        const bool row_ok = (unsigned)iy < (unsigned)a.H_in;
+        const int soff = row_ok ? (img_row0 + iy) * a.W_in * a.in_ld * 2 : 0;
+        char* dst = buf + r * rowbytes;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k * 64 < rowslots && k * 64 + lane < rowslots)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + k * 1024), 16,
+                                                     (int)(row_ok ? voff[k] : 0x80000000u), soff, 0, 0);
+        }
+      }
+    };
+    const bool active = jl < NTL;
+    const int hh = a.halo_h;
+    // with a mid-stage barrier the issue is split around it, so no barrier waits for a whole tile's issue
+    const int rsplit = resident ? hh : (hh + 1) / 2;
+    if (active && jl < S) issue(jl, 0, hh);
+    int mine = jl;                                       // next stage this loader has to deliver
+#ifdef RTPE_CONV_STAMPS
+    unsigned long long t0, t1, t2, t3, twait = 0, tissue = 0;
+#endif
+    for (int s = 0; s < S; ++s) {
+      const bool own = active && s == mine;
+      SSTAMP(t0);
+      if (own) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile s has landed
+      SSTAMP(t1);
+      RTPE_SBARRIER();                                   // M(s): buffer (s-1) % NB is free
+      SSTAMP(t2);
+      if (own) mine += NTL;
+      const bool more = own && mine < S;
+      if (more) issue(mine, 0, rsplit);
+      SSTAMP(t3);
+      if (!resident) {
+        RTPE_SBARRIER();                                 // H(s)
+        if (more) issue(mine, rsplit, hh);
+      }
+      if ((s & (ncc - 1)) == ncc - 1) RTPE_SBARRIER();   // E(s)
+#ifdef RTPE_CONV_STAMPS
+      twait += t1 - t0; tissue += t3 - t2;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RTPE_CONV_STAMPS
+    if (a.dbg != nullptr && lane == 0) { atomicAdd(&a.dbg[8], twait); atomicAdd(&a.dbg[9], tissue); }
+#endif
+    return;
+  }
+
+  // -------------------------------- MFMA waves --------------------------------
+  const int r = lane & 15;
+  const int g = lane >> 4;
+  // LDS byte offset of this lane group's 8 channels in k-step k (flat [tap][channel] order)
+  int toff[kKC];
+#pragma unroll
+  for (int k = 0; k < kKC; ++k) {
+    int kk = k * 32 + g * 8;
+    if (kk >= 9 * kCC) kk -= 9 * kCC;                   // zero-weight k padding: any finite in-tile data
+    const int tap = kk / kCC, c = kk - tap * kCC;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    toff[k] = (ty * a.halo_w + tx) * kPStride + c * 2;
+  }
+  int pixbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const uint32_t p = (wv * NT + nt) * 16 + r;
+    const uint32_t oy = fdiv(p, a.div_tw);
+    const uint32_t ox = p - oy * a.tw;
+    pixbase[nt] = (int)((oy * a.halo_w + ox) * kPStride);
+  }
+  constexpr int ROWB = MT * 32 + 16;
+  constexpr int CH = MT * 2;
+  constexpr int NIT = (NT * 16 * CH + 63) / 64;          // 16-byte row pieces per lane in the epilogue
+  // row piece `it` of this lane: pixel of the wave's slab, 16-byte slot, position in the tile
+  // (valid bit in the sign): fixed for the whole kernel
+  int edesc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    const int pw = c / CH, slot = c - pw * CH;
+    const uint32_t p = wv * NT * 16 + pw;
+    const uint32_t oyt = fdiv(p, a.div_tw);
+    const uint32_t oxt = p - oyt * a.tw;
+    edesc[it] = c < NT * 16 * CH ? (int)((pw << 16) | (slot << 12) | (oyt << 6) | oxt) : -1;
+  }
+
+  float4v acc[MT][NT];
+  half8 rres[NIT];
+  float4v al[MT], be[MT];
+  int tile = 0, cb = 0;
+  uint32_t n = 0;
+  int py0 = 0, px0 = 0;
+  int bsel = 0;                                          // s % NB
+  int wsel = 0;                                          // (2 s) % 3
+
+  // one half stage: 7 k-steps, operands of step k+1 are requested before the MFMAs of step k
+  auto half_stage = [&](const char* wslot, const char* tilebuf, auto hsel) {
+    constexpr int H = decltype(hsel)::value;
+    const char* wl = wslot + lane * 16;
+    half8 af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const half8*>(tilebuf + pixbase[nt] + toff[H * kKH]);
+#pragma unroll
+    for (int kk = 0; kk < kKH; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < kKH) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 1) * MT + m) * 1024);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bf[nxt][nt] = *reinterpret_cast<const half8*>(tilebuf + pixbase[nt] + toff[H * kKH + kk + 1]);
+      }
+      // all LDS reads of step k+1 are in flight before the MFMA burst of step k starts
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc[m][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long c0, c1, c2, c3, c4, c5 = 0, s_waitm = 0, s_h0 = 0, s_waith = 0, s_h1 = 0, s_other = 0;
+  unsigned long long e0, e1, e2, e3, s_ewait = 0, s_etr = 0, s_est = 0;
+#endif
+  for (int s = 0; s < S; ++s) {
+    const int cci = s & (ncc - 1);
+    if (cci == 0) {
+      um.get(s >> sh, &tile, &cb);
+      uint32_t t = (uint32_t)tile;
+      n = fdiv(t, a.div_tiles_xy);
+      t -= n * tiles_xy;
+      const uint32_t tyi = fdiv(t, a.div_tiles_x);
+      const uint32_t txi = t - tyi * a.tiles_x;
+      py0 = (int)tyi * a.th;
+      px0 = (int)txi * a.tw;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool last = cci == ncc - 1;
+    if (last) {
+      int g_p = g;
+      asm volatile("" : "+v"(g_p));                      // keep these loads inside the stage loop
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int c4 = (cb * MT + m) * 16 + g_p * 4;
+        al[m] = *reinterpret_cast<const float4v*>(a.alpha + c4);
+        be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
+      }
+      if (a.res != nullptr) {
+        // residual rows of this unit: requested now, they land while the last k-steps run
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          int d = edesc[it];
+          asm volatile("" : "+v"(d));
+          const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7;
+          const int py = py0 + oyt, px = px0 + oxt;
+          const int ch = cb * MT * 16 + slot * 8;
+          rres[it] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (d >= 0 && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
+            const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+            const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
+            rres[it] = *reinterpret_cast<const half8*>(a.res + pix * a.res_ld + ch);
+          }
+        }
+      }
+    }
+    char* tilebuf = tiles + bsel * a.buf_bytes;
+    const int w0 = resident ? 2 * cci : wsel;
+    const int w1 = resident ? 2 * cci + 1 : (wsel == 2 ? 0 : wsel + 1);
+    SSTAMP(c0);
+    RTPE_SBARRIER();                                     // M(s): tile s and weight half 2s are in LDS
+    SSTAMP(c1);
+    half_stage(wring + w0 * WSLOT, tilebuf, std::integral_constant<int, 0>());
+    SSTAMP(c2);
+    if (!resident) RTPE_SBARRIER();                      // H(s): weight half 2s+1 is in LDS
+    SSTAMP(c3);
+    half_stage(wring + w1 * WSLOT, tilebuf, std::integral_constant<int, 1>());
+    SSTAMP(c4);
+#ifdef RTPE_CONV_STAMPS
+    if (s > 0) s_other += c0 - c5;
+    s_waitm += c1 - c0; s_h0 += c2 - c1; s_waith += c3 - c2; s_h1 += c4 - c3;
+#endif
+    if (last) {
+      // ---- epilogue: BN/bias (+ residual) (+ ReLU), transposed through LDS ----
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));                   // lane-only math must not be hoisted out of the loop
+      const int re = lane_e & 15, ge = lane_e >> 4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SSTAMP(e0);
+      RTPE_SBARRIER();                                   // E(s): every MFMA wave is done with the tile
+      SSTAMP(e1);
+      char* obuf = tilebuf + wv * (NT * 16 * ROWB);
+      // BN / bias with the wrapper's rounding points, two channels per VALU op where the ISA allows it
+      auto bn_to_lds = [&](auto rc) {
+        constexpr bool RC = decltype(rc)::value;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4v v = acc[m][nt];
+            float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+            if (RC) {                                    // the conv output is an fp16 tensor
+              lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+              hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
+            }
+            lo = __builtin_elementwise_fma(lo, float2v{al[m][0], al[m][1]}, float2v{be[m][0], be[m][1]});
+            hi = __builtin_elementwise_fma(hi, float2v{al[m][2], al[m][3]}, float2v{be[m][2], be[m][3]});
+            const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+            const half4 o{olo[0], olo[1], ohi[0], ohi[1]};
+            *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * ROWB + m * 32 + ge * 8) = o;
+            if (a.y_nchw != nullptr) {                   // heads: NCHW straight from the registers
+              const uint32_t p = (wv * NT + nt) * 16 + re;
+              const uint32_t oyt = fdiv(p, a.div_tw);
+              const uint32_t oxt = p - oyt * a.tw;
+              const int py = py0 + (int)oyt, px = px0 + (int)oxt;
+              if (py < a.H_pos && px < a.W_pos) {
+                const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+                const int c4 = (cb * MT + m) * 16 + ge * 4;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                  const int c = c4 + jx;
+                  if (c < a.nchw_channels) {
+                    const float xr = (float)o[jx];
+                    const float x = a.relu ? (xr > 0.f ? xr : 0.f) : xr;
+                    const size_t oi = (((size_t)n * a.nchw_channels + c) * a.H_full + oy) * a.W_full + ox;
+                    if (a.nchw_f32)
+                      reinterpret_cast<float*>(a.y_nchw)[oi] = x;
+                    else
+                      reinterpret_cast<_Float16*>(a.y_nchw)[oi] = (_Float16)x;
+                  }
+                }
+              }
+            }
+          }
+        }
+      };
+      if (a.round_conv) bn_to_lds(std::true_type()); else bn_to_lds(std::false_type());
+      const int cblk = cb * MT * 16;
+      SSTAMP(e2);
+      if (a.y != nullptr) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          int d = edesc[it];
+          asm volatile("" : "+v"(d));
+          if (d < 0) continue;
+          const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7, pw = d >> 16;
+          const int py = py0 + oyt, px = px0 + oxt;
+          const int ch = cblk + slot * 8;
+          if (py >= a.H_pos || px >= a.W_pos || ch >= a.cout_store) continue;
+          const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+          const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
+          half8 v = *reinterpret_cast<const half8*>(obuf + pw * ROWB + slot * 16);
+          if (a.res != nullptr) v = v + rres[it];          // fp16 add, round-to-nearest-even = the wrapper's add
+          if (a.relu) {                                    // x > 0 ? x : +0, on the sign bits
+            short8 b = __builtin_bit_cast(short8, v);
+            b = b & ~(b >> 15);
+            v = __builtin_bit_cast(half8, b);
+          }
+          *reinterpret_cast<half8*>(a.y + pix * a.out_ld + ch) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic on the buffer is over
+      SSTAMP(e3);
+#ifdef RTPE_CONV_STAMPS
+      s_ewait += e1 - e0; s_etr += e2 - e1; s_est += e3 - e2;
+#endif
+    }
+    bsel = bsel + 1 == NB ? 0 : bsel + 1;
+    wsel = wsel == 0 ? 2 : wsel - 1;                     // (2 (s+1)) % 3 = (wsel + 2) % 3
+    SSTAMP(c5);
+  }
+#ifdef RTPE_CONV_STAMPS
+  if (a.dbg != nullptr && lane == 0) {
+    atomicAdd(&a.dbg[0], s_waitm); atomicAdd(&a.dbg[1], s_h0); atomicAdd(&a.dbg[2], s_waith);
+    atomicAdd(&a.dbg[3], s_h1); atomicAdd(&a.dbg[4], s_other); atomicAdd(&a.dbg[5], (unsigned long long)S);
+    atomicAdd(&a.dbg[12], s_ewait); atomicAdd(&a.dbg[13], s_etr); atomicAdd(&a.dbg[14], s_est);
+  }
+#endif
+}
+
+template <int MT, int NT, int WAVES>
+static int launch_stream(const ConvTile& t, const ConvArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_stream_kernel<MT, NT, WAVES>;
+  if (!attr_set) {
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3((WAVES + kLoaders) * 64), t.lds_bytes, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+// LDS of one workgroup: n_wslots weight half-stage slots (3 = streaming ring, 2 * n_cchunks =
+// resident) + n_bufs halo tile buffers
+size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots) {
+  return (size_t)n_wslots * p.mt * kKH * 1024 + (size_t)n_bufs * buf_bytes;
+}
+
+bool conv_stream_supports(const ConvPlan& p) {
+  return p.esize == 2 && p.dil == 1 && p.cc == kCC && p.pstride == kPStride && p.tapw == 3 && p.kc == kKC &&
+         p.in_mul == 1 && p.mt <= 3 && (p.n_cchunks & (p.n_cchunks - 1)) == 0;
+}
+
+int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
+  RTPE_REQUIRE(conv_stream_supports(p), "streaming conv: unsupported plan");
+  RTPE_REQUIRE(a.x_bytes > 0 && a.x_bytes < 0x80000000ull, "streaming conv: input view of %zu bytes", (size_t)a.x_bytes);
+  RTPE_REQUIRE(a.cin % 8 == 0 && a.in_ld >= a.cin, "streaming conv: cin=%d in_ld=%d", a.cin, a.in_ld);
+  RTPE_REQUIRE(t.grid >= 8 && t.grid % 8 == 0 && (t.grid / 8) % p.n_cb == 0, "streaming conv: bad grid %d", t.grid);
+  RTPE_REQUIRE((t.n_bufs == 2 || t.n_bufs == 3) && t.buf_bytes % 16 == 0 &&
+               (t.n_wslots == 3 || t.n_wslots == 2 * p.n_cchunks) &&
+               t.lds_bytes >= conv_stream_lds(p, t.buf_bytes, t.n_bufs, t.n_wslots) && t.lds_bytes <= 160 * 1024,
+               "streaming conv: LDS layout (%d buffers of %d B, %d weight slots, %zu B)", t.n_bufs, t.buf_bytes,
+               t.n_wslots, t.lds_bytes);
+  RTPE_REQUIRE(a.halo_w * kSlots <= 256, "streaming conv: halo row of %d pixels", a.halo_w);
+  RTPE_REQUIRE((size_t)a.halo_h * a.halo_w * kPStride <= (size_t)t.buf_bytes &&
+               (size_t)t.waves * t.nt * 16 * (p.mt * 32 + 16) <= (size_t)t.buf_bytes, "streaming conv: tile buffer too small");
+#define RTPE_S(MTv, NTv, Wv) \
+  if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_stream<MTv, NTv, Wv>(t, a, s);
+  RTPE_S(3, 4, 4) RTPE_S(3, 5, 4) RTPE_S(3, 5, 5)
+  RTPE_S(2, 4, 4) RTPE_S(2, 5, 4) RTPE_S(2, 5, 5)
+  RTPE_S(1, 4, 4) RTPE_S(1, 5, 4) RTPE_S(1, 5, 5)
+#undef RTPE_S
+  set_error("streaming conv: no kernel variant mt=%d nt=%d waves=%d", p.mt, t.nt, t.waves);
+  return RTPE_E_INVALID;
+}
+
+}  // namespace rtpe

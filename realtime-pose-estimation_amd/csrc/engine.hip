@@ -470,7 +470,12 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   unsigned long long hd[16];
   hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost);
   hipFree(dbg);
-  if (hd[5])
+  if (tile.kind == 2 && hd[5] && (hd[11] = hd[11] ? hd[11] : hd[5] / tile.waves))
+    fprintf(stderr, "stream conv %dx%d nt%d w%d nb%d nw%d grid %d | per MFMA-wave stage: waitM %llu half0 %llu waitH %llu half1 %llu "
+            "setup %llu E-wait %llu transpose %llu add+store %llu | weight loader/stage: wait %llu issue %llu | tile loaders/stage: wait %llu issue %llu\n",
+            tile.th, tile.tw, tile.nt, tile.waves, tile.n_bufs, tile.n_wslots, tile.grid, hd[0] / hd[5], hd[1] / hd[5], hd[2] / hd[5],
+            hd[3] / hd[5], hd[4] / hd[5], hd[12] / hd[5], hd[13] / hd[5], hd[14] / hd[5], hd[6] / hd[11], hd[7] / hd[11], hd[8] / hd[11], hd[9] / hd[11]);
+  else if (hd[5])
     fprintf(stderr, "conv stamps (kind %d): n %llu | per wave(-unit) cycles: setup %llu stage/wait1 %llu kloop %llu epilogue %llu total/wait2 %llu\n",
             tile.kind, hd[5], hd[0] / hd[5], hd[1] / hd[5], hd[2] / hd[5], hd[3] / hd[5], hd[4] / hd[5]);
   if (hd[10])
@@ -508,7 +513,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     if (it != h->tuned.end() && it->second[op * 4].nt) t = it->second[op * 4];
   }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind ? -t.grid : (int32_t)t.lds_bytes;
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 1 ? -t.grid : (int32_t)t.lds_bytes;
   return RTPE_OK;
 }
 

@@ -77,7 +77,9 @@ struct ConvArgs {
   FastDiv div_tw, div_slots, div_rowslots, div_cc, div_tiles_x, div_tiles_xy;
   size_t x_bytes;        // bytes from x to the end of its tensor (buffer bounds of the LDS-DMA path)
   int n_cb;              // cout blocks
-  int buf_bytes;         // persistent kernel: bytes of one LDS tile buffer
+  int buf_bytes;         // persistent / streaming kernel: bytes of one LDS tile buffer
+  int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
+  int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
   unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
 
@@ -94,9 +96,12 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int nt, waves;        // pixel tiles (x16) per wave, MFMA waves per workgroup
   int th, tw;
   size_t lds_bytes;
-  int kind;             // 0: one workgroup per tile (conv_mfma.hip), 1: persistent + loader wave (conv_persist.hip)
-  int grid;             // persistent: number of workgroups
-  int buf_bytes;        // persistent: one LDS tile buffer
+  int kind;             // 0: one workgroup per tile (conv_mfma.hip), 1: persistent + loader wave (conv_persist.hip),
+                        // 2: streaming, weights and halos by LDS-DMA (conv_stream.hip)
+  int grid;             // persistent / streaming: number of workgroups
+  int buf_bytes;        // persistent / streaming: one LDS tile buffer
+  int n_bufs;           // streaming: halo tile buffers
+  int n_wslots;         // streaming: weight half-stage slots
 };
 
 struct ConvGeom {       // logical layer, independent of the batch
@@ -116,6 +121,9 @@ void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w, void
 void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, ConvArgs* a);
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int conv_persist_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+bool conv_stream_supports(const ConvPlan& p);
+size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots);
+int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 
 // ---- elementwise / stem (elementwise.hip) ---------------------------------
 struct FuseArgs {
