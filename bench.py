@@ -163,10 +163,26 @@ def main():
     total_flops = sum(c[0] for c in costs)
     total_bytes = sum(c[1] for c in costs)
     fwd_ms_events = float(op_ms.sum())
+    dom_tiles = [eng.op_tile(i, B, S, S) for i in dom_idx]
+    dom_kernel = "conv_stream_kernel" if all(t[7] <= -100000 for t in dom_tiles) else \
+        "conv_mfma_kernel" if all(t[7] > 0 for t in dom_tiles) else "conv_stream_kernel / conv_mfma_kernel"
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured with
+    # rocprofv3 on this kernel and committed under profiles/ (bench.py cannot run the profiler on itself)
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("kernel", "").startswith(dom_kernel) and tj.get("batch") == B:
+                traffic, traffic_src = float(tj["hbm_bytes_per_launch"]["mean"]), "profiles/r01_hbm_traffic.json"
+        except (ValueError, KeyError):
+            pass
     roofline = {
-        "kernel": "conv_mfma_kernel<3,*,4> 3x3 s1 48->48 @160x160 (BasicBlock conv, %d launches/forward)" % len(dom_idx),
+        "kernel": "%s<3,*,4> 3x3 s1 48->48 @160x160 (BasicBlock conv, %d launches/forward)" % (dom_kernel, len(dom_idx)),
         "bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+        "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_source": traffic_src,
         "launch_us": round(dom_ms * 1e3, 2), "bytes_per_launch": dom_bytes,
         "mfma_tflops": round(dom_flops / (dom_ms * 1e-3) / 1e12, 1),
         "forward_tflops": round(total_flops / (fwd_ms_events * 1e-3) / 1e12, 1),

@@ -124,17 +124,68 @@ __global__ void __launch_bounds__(256) bilinear_kernel(BilinearMap m, int planes
 
 constexpr int kTH = 32, kTW = 64;   // NMS / top-k tile (2048 px, 8 per thread)
 constexpr int kMaxPad = 4;          // supports nms kernels up to 9x9
+constexpr int kMaxCand = 512;       // local maxima of a tile handled by the one-pass rank sort
+
+// per-tile samples of the (virtual) full-resolution map.  For the bilinear sampler the two
+// axis computations are done once per tile row / column (tables in LDS) instead of once per
+// sample; the per-sample arithmetic is exactly BilinearMap::at's.
+struct AxisTab {
+  int i0[kTW + 2 * kMaxPad], i1[kTW + 2 * kMaxPad];
+  float l0[kTW + 2 * kMaxPad], l1[kTW + 2 * kMaxPad];
+};
 
 template <class Map>
-__device__ __forceinline__ void nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
-                                         float* raw, float* rowmax) {
-  // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
+__device__ __forceinline__ void fill_raw(const Map& m, int plane, int h, int w, int y0, int x0, int pad, float* raw,
+                                         AxisTab*, AxisTab*) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH * PW; i += 256) {
     const int py = i / PW, px = i - py * PW;
     const int y = y0 - pad + py, x = x0 - pad + px;
     raw[i] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? m.at(plane, y, x) : -INFINITY;
   }
+}
+
+template <>
+__device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int plane, int h, int w, int y0, int x0,
+                                                      int pad, float* raw, AxisTab* ty, AxisTab* tx) {
+  const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
+  for (int i = threadIdx.x; i < PH + PW; i += 256) {
+    const bool isy = i < PH;
+    const int k = isy ? i : i - PH;
+    const int o = (isy ? y0 : x0) - pad + k;
+    AxisTab* t = isy ? ty : tx;
+    const int lim = isy ? h : w;
+    int a0 = -1, a1 = -1;
+    float f0 = 0.f, f1 = 0.f;
+    if ((unsigned)o < (unsigned)lim) (isy ? m.ay : m.ax).at(o, &a0, &a1, &f0, &f1);
+    t->i0[k] = a0; t->i1[k] = a1; t->l0[k] = f0; t->l1[k] = f1;
+  }
+  __syncthreads();
+  const int n = plane / m.J, j = plane - n * m.J;
+  const float* b = m.p + (size_t)n * m.img_stride + (size_t)j * m.sh * m.sw;
+  for (int i = threadIdx.x; i < PH * PW; i += 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int r0 = ty->i0[py], c0 = tx->i0[px];
+    float v = -INFINITY;
+    if (r0 >= 0 && c0 >= 0) {
+      const int r1 = ty->i1[py], c1 = tx->i1[px];
+      const float ly0 = ty->l0[py], ly1 = ty->l1[py], lx0 = tx->l0[px], lx1 = tx->l1[px];
+      const float v00 = b[r0 * m.sw + c0], v01 = b[r0 * m.sw + c1];
+      const float v10 = b[r1 * m.sw + c0], v11 = b[r1 * m.sw + c1];
+      const float t0 = __builtin_fmaf(v00, lx0, v01 * lx1);
+      const float t1 = __builtin_fmaf(v10, lx0, v11 * lx1);
+      v = __builtin_fmaf(t0, ly0, t1 * ly1);
+    }
+    raw[i] = v;
+  }
+}
+
+template <class Map>
+__device__ __forceinline__ void nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
+                                         float* raw, float* rowmax, AxisTab* ty, AxisTab* tx) {
+  // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
+  const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
+  fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx);
   __syncthreads();
   for (int i = threadIdx.x; i < PH * kTW; i += 256) {
     const int py = i / kTW, px = i - py * kTW;
@@ -152,7 +203,8 @@ __global__ void __launch_bounds__(256) nms_kernel(Map m, int h, int w, int pad, 
   const int tiles_x = (w + kTW - 1) / kTW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
   const int y0 = ty * kTH, x0 = tx * kTW;
-  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax);
+  __shared__ AxisTab taby, tabx;
+  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx);
   const int PW = kTW + 2 * pad;
   for (int i = threadIdx.x; i < kTH * kTW; i += 256) {
     const int ly = i / kTW, lx = i - ly * kTW;
@@ -176,7 +228,11 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
   const int tiles_x = (w + kTW - 1) / kTW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
   const int y0 = ty * kTH, x0 = tx * kTW;
-  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax);
+  __shared__ AxisTab taby, tabx;
+  __shared__ u64 clist[kMaxCand];
+  __shared__ int ccount;
+  if (threadIdx.x == 0) ccount = 0;
+  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx);
   const int PW = kTW + 2 * pad;
   u64 mine[8];   // this thread's 8 pixels as keys (0 = not a positive local maximum)
 #pragma unroll
@@ -192,8 +248,27 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
       if (mx == v && v > 0.f) key = make_key(v, (unsigned)(y * w + x));
     }
     mine[q] = key;
+    if (key != 0) {                 // compact the (few) local maxima of the tile
+      const int pos = atomicAdd(&ccount, 1);
+      if (pos < kMaxCand) clist[pos] = key;
+    }
   }
+  __syncthreads();
   u64* outp = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;
+  const int nc = ccount;
+  if (nc <= kMaxCand) {
+    // rank sort: keys are unique (the pixel index is part of the key), so the rank of a key is
+    // the number of larger ones; one pass, no further barriers
+    for (int t = threadIdx.x; t < nc; t += 256) {
+      const u64 key = clist[t];
+      int rank = 0;
+      for (int j = 0; j < nc; ++j) rank += clist[j] > key ? 1 : 0;
+      if (rank < K) outp[rank] = key;
+    }
+    for (int r = nc + threadIdx.x; r < K; r += 256) outp[r] = 0;
+    return;
+  }
+  // plateau-heavy tile (more local maxima than the list holds): K rounds of a block-wide max
   for (int k = 0; k < K; ++k) {
     u64 best = mine[0];
 #pragma unroll

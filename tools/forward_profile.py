@@ -1,0 +1,74 @@
+"""GPU probe: per-op-class HIP-event times of the teacher forward ALONE (no decode on a side
+stream), batch 32 at 640x640 by default.
+
+    python tools/forward_profile.py [batch] [size] [out.txt]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import __graft_entry__ as entry  # noqa: E402
+
+entry.build()
+from rtpe.helpers import build_hrnet_w48_teacher  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+    out = sys.argv[3] if len(sys.argv) > 3 else None
+    torch.manual_seed(0)
+    model = build_hrnet_w48_teacher().to("cuda:0")
+    net = model[1]
+    x = torch.randn(B, 3, S, S, device="cuda:0")
+    with torch.no_grad():
+        model(x)
+    eng = net._engine(x.device)
+    reps = 5
+    acc = None
+    for _ in range(reps):
+        _, ms = eng.forward_timed(x)
+        acc = np.array(ms) if acc is None else acc + np.array(ms)
+    acc /= reps
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.forward(x)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 5 * 1e3
+    names = list(eng.program.names)
+    by = {}
+    for i, nm in enumerate(names):
+        t = eng.op_tile(i, B, S, S)
+        op = eng.program.ops[i]
+        ds = eng.program.tensors[op.out_t].ds_log2 if op.out_t >= 0 else 1
+        tag = ""
+        if t[0]:
+            kind = (" S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else ""
+            tag = " [m%d n%d w%d %dx%d cc%d cb%d%s]" % (tuple(t[:7]) + (kind,))
+        key = "%s @/%d%s" % (nm, 1 << ds, tag)
+        c = eng.op_cost(i, B, S, S)
+        d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += acc[i]
+        d[2] += c[0]
+        d[3] += c[1]
+    lines = ["# forward only, batch %d, %dx%d, per-op HIP events averaged over %d passes" % (B, S, S, reps),
+             "%-68s %3s %9s %9s %9s %8s" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op")]
+    for k, d in sorted(by.items(), key=lambda kv: -kv[1][1]):
+        lines.append("%-68s %3d %9.3f %9.1f %9.1f %8.1f" % (k, d[0], d[1], d[2] / d[1] / 1e9, d[3] / d[1] / 1e6,
+                                                         d[1] / d[0] * 1e3))
+    lines.append("forward total (events) %.3f ms; wall %.3f ms = %.1f img/s" % (acc.sum(), wall, B / wall * 1e3))
+    txt = "\n".join(lines)
+    print(txt)
+    if out:
+        open(out, "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,26 +1,62 @@
-"""Summarise a rocprofv3 kernel_trace.csv: per (kernel, grid, block, lds) call count and mean/min us."""
+"""Summarise a rocprofv3 kernel_trace.csv: per kernel call count and mean / min / total us.
+
+    python tools/trace_summary.py [--last-forwards K] [--csv out.csv] trace.csv ...
+
+--last-forwards K keeps only the dispatches from the start of the K-th last forward pass on
+(one stem_kernel launch per forward), i.e. the timed steps of bench.py without warm-up and
+autotuning passes.
+"""
+import argparse
 import collections
 import csv
 import glob
-import sys
 
 
-def main(paths):
-    for pat in paths:
+def short(name):
+    name = name.replace("void rtpe::", "").replace("rtpe::", "")
+    if name.startswith("_ZN4rtpe"):
+        import re
+        m = re.match(r"_ZN4rtpe(\d+)([A-Za-z_0-9]+)", name)
+        if m:
+            base = m.group(2)[:int(m.group(1))]
+            args = re.findall(r"Li(\d+)E", name)
+            name = base + ("<" + ",".join(args) + ">" if args else "")
+    return name.split("(")[0][:60]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--last-forwards", type=int, default=0)
+    ap.add_argument("--csv", default=None)
+    ap.add_argument("paths", nargs="*", default=["gpurun_out/**/*kernel_trace.csv"])
+    a = ap.parse_args()
+    for pat in a.paths:
         for path in sorted(glob.glob(pat, recursive=True)):
+            rows = list(csv.DictReader(open(path)))
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            if a.last_forwards:
+                stems = [int(r["Start_Timestamp"]) for r in rows if "stem_kernel" in r["Kernel_Name"]]
+                if len(stems) >= a.last_forwards:
+                    t0 = stems[-a.last_forwards]
+                    rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
             agg = collections.OrderedDict()
-            for r in csv.DictReader(open(path)):
-                name = r["Kernel_Name"].replace("void rtpe::", "").split("(")[0][:44]
-                key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"], r["LDS_Block_Size"],
-                       r["VGPR_Count"])
+            for r in rows:
+                key = (short(r["Kernel_Name"]), r["Workgroup_Size_X"], r["VGPR_Count"])
                 agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-            print("==", path)
+            total = sum(sum(v) for v in agg.values())
+            span = (max(int(r["End_Timestamp"]) for r in rows) - min(int(r["Start_Timestamp"]) for r in rows)) / 1e3
+            print("== %s: %d dispatches, kernel time %.1f us over a span of %.1f us" % (path, len(rows), total, span))
+            out = [("kernel", "workgroup", "vgpr", "calls", "total_us", "mean_us", "min_us", "pct")]
             for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-                if sum(v) < 5:
-                    continue
-                print("%-44s grid %8s x%-4s wg %4s lds %6s vgpr %4s  n=%-4d mean %9.1f us  min %9.1f" % (
-                    k + (len(v), sum(v) / len(v), min(v))))
+                out.append(k + (len(v), round(sum(v), 1), round(sum(v) / len(v), 2), round(min(v), 2),
+                                round(100 * sum(v) / total, 2)))
+            for o in out[:40]:
+                print("%-60s wg %5s vgpr %5s n=%-5s total %11s mean %9s min %9s %6s" % o)
+            if a.csv:
+                with open(a.csv, "w") as f:
+                    for o in out:
+                        f.write(",".join(str(x) for x in o) + "\n")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["gpurun_out/**/*kernel_trace.csv"])
+    main()
