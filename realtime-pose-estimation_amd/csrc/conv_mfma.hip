@@ -580,6 +580,8 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
+  static const int abl = getenv("RTPE_STREAM_ABL") ? atoi(getenv("RTPE_STREAM_ABL")) : 0;
+  a->ablate = abl;
   // ablation for profiling only: RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
   static const int skipk = getenv("RTPE_CONV_SKIPK") ? atoi(getenv("RTPE_CONV_SKIPK")) : 0;
   if (skipk) a->kc = 0;

@@ -57,6 +57,22 @@ __device__ __forceinline__ float round16s(float v) { return (float)(_Float16)v; 
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction only takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define RTPE_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+  switch (n) {
+    RTPE_W(1) RTPE_W(2) RTPE_W(3) RTPE_W(4) RTPE_W(5) RTPE_W(6) RTPE_W(7) RTPE_W(8) RTPE_W(9) RTPE_W(10)
+    RTPE_W(11) RTPE_W(12) RTPE_W(13) RTPE_W(14) RTPE_W(15) RTPE_W(16) RTPE_W(17) RTPE_W(18) RTPE_W(19) RTPE_W(20)
+    RTPE_W(21) RTPE_W(22) RTPE_W(23) RTPE_W(24) RTPE_W(25) RTPE_W(26) RTPE_W(27) RTPE_W(28) RTPE_W(29) RTPE_W(30)
+    RTPE_W(31) RTPE_W(32) RTPE_W(33) RTPE_W(34) RTPE_W(35) RTPE_W(36) RTPE_W(37) RTPE_W(38) RTPE_W(39) RTPE_W(40)
+    RTPE_W(41) RTPE_W(42) RTPE_W(43) RTPE_W(44) RTPE_W(45) RTPE_W(46) RTPE_W(47) RTPE_W(48) RTPE_W(49) RTPE_W(50)
+    RTPE_W(51) RTPE_W(52) RTPE_W(53) RTPE_W(54) RTPE_W(55) RTPE_W(56) RTPE_W(57) RTPE_W(58) RTPE_W(59) RTPE_W(60)
+    RTPE_W(61) RTPE_W(62) RTPE_W(63)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, or more than the counter holds
+  }
+#undef RTPE_W
+}
+
 #ifdef RTPE_CONV_STAMPS
 #define SSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -170,7 +186,6 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
   if (wv > WAVES) {
     // ------------------------------ tile loaders ------------------------------
     const int jl = wv - WAVES - 1;                       // 0 or 1
-    const int NTL = NB - 1;                              // active tile loaders
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const int rowslots = a.halo_w * kSlots;
@@ -204,35 +219,38 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
         char* dst = buf + r * rowbytes;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (k * 64 < rowslots && k * 64 + lane < rowslots)
+          if (k * 64 < rowslots && k * 64 + lane < rowslots && !(a.ablate & 4))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + k * 1024), 16,
                                                      (int)(row_ok ? voff[k] : 0x80000000u), soff, 0, 0);
         }
       }
     };
-    const bool active = jl < NTL;
+    // both loaders work on EVERY tile (one half of its rows each): two instruction streams feed the
+    // memory pipeline, and a tile is requested P = NB - 1 stages before it is multiplied
     const int hh = a.halo_h;
-    // with a mid-stage barrier the issue is split around it, so no barrier waits for a whole tile's issue
-    const int rsplit = resident ? hh : (hh + 1) / 2;
-    if (active && jl < S) issue(jl, 0, hh);
-    int mine = jl;                                       // next stage this loader has to deliver
+    const int P = NB - 1;
+    const int ra = jl == 0 ? 0 : hh / 2, rb = jl == 0 ? hh / 2 : hh;     // this loader's rows
+    const int rmid = resident ? rb : (ra + rb + 1) / 2;   // with a mid-stage barrier the issue is split around it
+    const int krow = (rowslots + 63) >> 6;
+    const int n_part = (rb - ra) * krow;                 // DMA instructions of one part
+    for (int t = 0; t < P && t < S; ++t) issue(t, ra, rb);
 #ifdef RTPE_CONV_STAMPS
     unsigned long long t0, t1, t2, t3, twait = 0, tissue = 0;
 #endif
     for (int s = 0; s < S; ++s) {
-      const bool own = active && s == mine;
       SSTAMP(t0);
-      if (own) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile s has landed
+      // this loader's part of tile s has landed; with P == 2 its part of tile s+1 may still be in flight
+      if (P == 2 && s + 1 < S) wait_vmcnt(n_part);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SSTAMP(t1);
       RTPE_SBARRIER();                                   // M(s): buffer (s-1) % NB is free
       SSTAMP(t2);
-      if (own) mine += NTL;
-      const bool more = own && mine < S;
-      if (more) issue(mine, 0, rsplit);
+      const bool more = s + P < S;
+      if (more) issue(s + P, ra, rmid);
       SSTAMP(t3);
       if (!resident) {
         RTPE_SBARRIER();                                 // H(s)
-        if (more) issue(mine, rsplit, hh);
+        if (more) issue(s + P, rmid, rb);
       }
       if ((s & (ncc - 1)) == ncc - 1) RTPE_SBARRIER();   // E(s)
 #ifdef RTPE_CONV_STAMPS
@@ -284,13 +302,28 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
   }
 
   float4v acc[MT][NT];
-  half8 rres[NIT];
-  float4v al[MT], be[MT];
-  int tile = 0, cb = 0;
-  uint32_t n = 0;
-  int py0 = 0, px0 = 0;
   int bsel = 0;                                          // s % NB
   int wsel = 0;                                          // (2 s) % 3
+  const int n_units = um.count;
+
+  // BN / bias parameters: a workgroup keeps its cout block (grid / 8 is a multiple of n_cb)
+  float4v al[MT], be[MT];
+  int cb0;
+  {
+    int tile0;
+    um.get(0, &tile0, &cb0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int c4 = (cb0 * MT + m) * 16 + g * 4;
+      al[m] = *reinterpret_cast<const float4v*>(a.alpha + c4);
+      be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)                           // read them here: the compiler's wait for these
+    asm volatile("" ::"v"(al[m]), "v"(be[m]));           // loads belongs in front of the unit loop
+  const int cblk = cb0 * MT * 16;
+  const bool use_res = a.res != nullptr && !(a.ablate & 2);
 
   // one half stage: 7 k-steps, operands of step k+1 are requested before the MFMAs of step k
   auto half_stage = [&](const char* wslot, const char* tilebuf, auto hsel) {
@@ -312,177 +345,189 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
         for (int nt = 0; nt < NT; ++nt)
           bf[nxt][nt] = *reinterpret_cast<const half8*>(tilebuf + pixbase[nt] + toff[H * kKH + kk + 1]);
       }
-      // all LDS reads of step k+1 are in flight before the MFMA burst of step k starts
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc[m][nt], 0, 0, 0);
+      // the LDS reads of step k+1 (and their address adds) are spread between the MFMAs of step k:
+      // the matrix pipe never waits for a burst of reads to be issued
+      if (kk + 1 < kKH) {
+#pragma unroll
+        for (int i = 0; i < MT + NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                       // VALU (address)
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-#ifdef RTPE_CONV_STAMPS
-  unsigned long long c0, c1, c2, c3, c4, c5 = 0, s_waitm = 0, s_h0 = 0, s_waith = 0, s_h1 = 0, s_other = 0;
-  unsigned long long e0, e1, e2, e3, s_ewait = 0, s_etr = 0, s_est = 0;
-#endif
-  for (int s = 0; s < S; ++s) {
-    const int cci = s & (ncc - 1);
-    if (cci == 0) {
-      um.get(s >> sh, &tile, &cb);
-      uint32_t t = (uint32_t)tile;
-      n = fdiv(t, a.div_tiles_xy);
-      t -= n * tiles_xy;
-      const uint32_t tyi = fdiv(t, a.div_tiles_x);
-      const uint32_t txi = t - tyi * a.tiles_x;
-      py0 = (int)tyi * a.th;
-      px0 = (int)txi * a.tw;
+  struct UnitPos { uint32_t n; int py0, px0; };
+  auto unit_pos = [&](int u) {
+    int tile, cb;
+    um.get(u, &tile, &cb);
+    uint32_t t = (uint32_t)tile;
+    UnitPos q;
+    q.n = fdiv(t, a.div_tiles_xy);
+    t -= q.n * tiles_xy;
+    const uint32_t tyi = fdiv(t, a.div_tiles_x);
+    const uint32_t txi = t - tyi * a.tiles_x;
+    q.py0 = (int)tyi * a.th;
+    q.px0 = (int)txi * a.tw;
+    return q;
+  };
+  // residual rows of unit u into one of the two register sets; they are requested TWO units
+  // before they are added, so an HBM round trip and the write acknowledgements queued in front
+  // of them (vmcnt completes in order) are off the critical path
+  // The loads are issued from inline asm: the compiler's own s_waitcnt insertion cannot follow a
+  // register set that is filled two units before it is read and answered with vmcnt(0) after
+  // every store; here the one wait that is needed is written by hand (run_unit).  Every lane
+  // loads (lanes without a valid row piece read the first row of the tensor and never store).
+  auto load_res = [&](int u, half8 (&rr)[NIT]) {
+    const UnitPos q = unit_pos(u);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < NIT; ++it) {
+      int d = edesc[it];
+      asm volatile("" : "+v"(d));                        // lane-only math must not be hoisted out of the unit loop
+      const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7;
+      const int py = q.py0 + oyt, px = q.px0 + oxt;
+      const int ch = cblk + slot * 8;
+      const bool ok = d >= 0 && py < a.H_pos && px < a.W_pos && ch < a.cout_store;
+      const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+      const size_t off = ok ? (((size_t)q.n * a.H_full + oy) * a.W_full + ox) * a.res_ld + ch : 0;
+      const _Float16* ptr = a.res + off;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[it]) : "v"(ptr) : "memory");
     }
-    const bool last = cci == ncc - 1;
-    if (last) {
-      int g_p = g;
-      asm volatile("" : "+v"(g_p));                      // keep these loads inside the stage loop
+  };
+
+  auto run_unit = [&](int u, half8 (&rr)[NIT]) {
+    const UnitPos q = unit_pos(u);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int c4 = (cb * MT + m) * 16 + g_p * 4;
-        al[m] = *reinterpret_cast<const float4v*>(a.alpha + c4);
-        be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    char* tilebuf = nullptr;
+    for (int cci = 0; cci < ncc; ++cci) {
+      tilebuf = tiles + bsel * a.buf_bytes;
+      const int w0 = resident ? 2 * cci : wsel;
+      const int w1 = resident ? 2 * cci + 1 : (wsel == 2 ? 0 : wsel + 1);
+      RTPE_SBARRIER();                                   // M(s): tile s and weight half 2s are in LDS
+      if (!(a.ablate & 1)) half_stage(wring + w0 * WSLOT, tilebuf, std::integral_constant<int, 0>());
+      if (!resident) RTPE_SBARRIER();                    // H(s): weight half 2s+1 is in LDS
+      if (!(a.ablate & 1)) half_stage(wring + w1 * WSLOT, tilebuf, std::integral_constant<int, 1>());
+      if (cci + 1 < ncc) {
+        bsel = bsel + 1 == NB ? 0 : bsel + 1;
+        wsel = wsel == 0 ? 2 : wsel - 1;                 // (2 (s+1)) % 3 = (wsel + 2) % 3
       }
-      if (a.res != nullptr) {
-        // residual rows of this unit: requested now, they land while the last k-steps run
+    }
+    // ---- epilogue: BN/bias (+ residual) (+ ReLU), transposed through LDS ----
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                     // as above: keep the epilogue's lane math in the loop
+    const int re = lane_e & 15, ge = lane_e >> 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RTPE_SBARRIER();                                     // E(s): every MFMA wave is done with the tile
+    char* obuf = tilebuf + wv * (NT * 16 * ROWB);
+    // BN / bias with the wrapper's rounding points, two channels per VALU op where the ISA allows it
+    auto bn_to_lds = [&](auto rc) {
+      constexpr bool RC = decltype(rc)::value;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          int d = edesc[it];
-          asm volatile("" : "+v"(d));
-          const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7;
-          const int py = py0 + oyt, px = px0 + oxt;
-          const int ch = cb * MT * 16 + slot * 8;
-          rres[it] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (d >= 0 && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
-            const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
-            const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
-            rres[it] = *reinterpret_cast<const half8*>(a.res + pix * a.res_ld + ch);
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float4v v = acc[m][nt];
+          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+          if (RC) {                                      // the conv output is an fp16 tensor
+            lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+            hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
           }
-        }
-      }
-    }
-    char* tilebuf = tiles + bsel * a.buf_bytes;
-    const int w0 = resident ? 2 * cci : wsel;
-    const int w1 = resident ? 2 * cci + 1 : (wsel == 2 ? 0 : wsel + 1);
-    SSTAMP(c0);
-    RTPE_SBARRIER();                                     // M(s): tile s and weight half 2s are in LDS
-    SSTAMP(c1);
-    half_stage(wring + w0 * WSLOT, tilebuf, std::integral_constant<int, 0>());
-    SSTAMP(c2);
-    if (!resident) RTPE_SBARRIER();                      // H(s): weight half 2s+1 is in LDS
-    SSTAMP(c3);
-    half_stage(wring + w1 * WSLOT, tilebuf, std::integral_constant<int, 1>());
-    SSTAMP(c4);
-#ifdef RTPE_CONV_STAMPS
-    if (s > 0) s_other += c0 - c5;
-    s_waitm += c1 - c0; s_h0 += c2 - c1; s_waith += c3 - c2; s_h1 += c4 - c3;
-#endif
-    if (last) {
-      // ---- epilogue: BN/bias (+ residual) (+ ReLU), transposed through LDS ----
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));                   // lane-only math must not be hoisted out of the loop
-      const int re = lane_e & 15, ge = lane_e >> 4;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      SSTAMP(e0);
-      RTPE_SBARRIER();                                   // E(s): every MFMA wave is done with the tile
-      SSTAMP(e1);
-      char* obuf = tilebuf + wv * (NT * 16 * ROWB);
-      // BN / bias with the wrapper's rounding points, two channels per VALU op where the ISA allows it
-      auto bn_to_lds = [&](auto rc) {
-        constexpr bool RC = decltype(rc)::value;
+          lo = __builtin_elementwise_fma(lo, float2v{al[m][0], al[m][1]}, float2v{be[m][0], be[m][1]});
+          hi = __builtin_elementwise_fma(hi, float2v{al[m][2], al[m][3]}, float2v{be[m][2], be[m][3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+          const half4 o{olo[0], olo[1], ohi[0], ohi[1]};
+          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * ROWB + m * 32 + ge * 8) = o;
+          if (a.y_nchw != nullptr) {                     // heads: NCHW straight from the registers
+            const uint32_t p = (wv * NT + nt) * 16 + re;
+            const uint32_t oyt = fdiv(p, a.div_tw);
+            const uint32_t oxt = p - oyt * a.tw;
+            const int py = q.py0 + (int)oyt, px = q.px0 + (int)oxt;
+            if (py < a.H_pos && px < a.W_pos) {
+              const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+              const int c4 = (cb0 * MT + m) * 16 + ge * 4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const float4v v = acc[m][nt];
-            float2v lo{v[0], v[1]}, hi{v[2], v[3]};
-            if (RC) {                                    // the conv output is an fp16 tensor
-              lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-              hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
-            }
-            lo = __builtin_elementwise_fma(lo, float2v{al[m][0], al[m][1]}, float2v{be[m][0], be[m][1]});
-            hi = __builtin_elementwise_fma(hi, float2v{al[m][2], al[m][3]}, float2v{be[m][2], be[m][3]});
-            const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
-            const half4 o{olo[0], olo[1], ohi[0], ohi[1]};
-            *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * ROWB + m * 32 + ge * 8) = o;
-            if (a.y_nchw != nullptr) {                   // heads: NCHW straight from the registers
-              const uint32_t p = (wv * NT + nt) * 16 + re;
-              const uint32_t oyt = fdiv(p, a.div_tw);
-              const uint32_t oxt = p - oyt * a.tw;
-              const int py = py0 + (int)oyt, px = px0 + (int)oxt;
-              if (py < a.H_pos && px < a.W_pos) {
-                const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
-                const int c4 = (cb * MT + m) * 16 + ge * 4;
-#pragma unroll
-                for (int jx = 0; jx < 4; ++jx) {
-                  const int c = c4 + jx;
-                  if (c < a.nchw_channels) {
-                    const float xr = (float)o[jx];
-                    const float x = a.relu ? (xr > 0.f ? xr : 0.f) : xr;
-                    const size_t oi = (((size_t)n * a.nchw_channels + c) * a.H_full + oy) * a.W_full + ox;
-                    if (a.nchw_f32)
-                      reinterpret_cast<float*>(a.y_nchw)[oi] = x;
-                    else
-                      reinterpret_cast<_Float16*>(a.y_nchw)[oi] = (_Float16)x;
-                  }
+              for (int jx = 0; jx < 4; ++jx) {
+                const int c = c4 + jx;
+                if (c < a.nchw_channels) {
+                  const float xr = (float)o[jx];
+                  const float x = a.relu ? (xr > 0.f ? xr : 0.f) : xr;
+                  const size_t oi = (((size_t)q.n * a.nchw_channels + c) * a.H_full + oy) * a.W_full + ox;
+                  if (a.nchw_f32)
+                    reinterpret_cast<float*>(a.y_nchw)[oi] = x;
+                  else
+                    reinterpret_cast<_Float16*>(a.y_nchw)[oi] = (_Float16)x;
                 }
               }
             }
           }
         }
-      };
-      if (a.round_conv) bn_to_lds(std::true_type()); else bn_to_lds(std::false_type());
-      const int cblk = cb * MT * 16;
-      SSTAMP(e2);
-      if (a.y != nullptr) {
+      }
+    };
+    if (a.round_conv) bn_to_lds(std::true_type()); else bn_to_lds(std::false_type());
+    if (a.y != nullptr && !(a.ablate & 2)) {
+      // the residual rows of THIS unit have landed: vmcnt completes in order and the only vector
+      // memory operations this wave is sure to have issued after them are the NIT loads of the
+      // next unit's rows (plus stores, which may then be older or newer: waiting for them is safe)
+      if (use_res) {
+        if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // all row pieces are read from LDS first (no control flow between the reads), then
+      // finished and stored: one LDS latency per unit instead of one per piece
+      half8 ov[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          int d = edesc[it];
-          asm volatile("" : "+v"(d));
-          if (d < 0) continue;
-          const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7, pw = d >> 16;
-          const int py = py0 + oyt, px = px0 + oxt;
-          const int ch = cblk + slot * 8;
-          if (py >= a.H_pos || px >= a.W_pos || ch >= a.cout_store) continue;
+      for (int it = 0; it < NIT; ++it) {
+        int d = edesc[it] & 0x7fffffff;
+        asm volatile("" : "+v"(d));
+        const int slot = (d >> 12) & 7, pw = (d >> 16) % (NT * 16);
+        ov[it] = *reinterpret_cast<const half8*>(obuf + pw * ROWB + slot * 16);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int d = edesc[it];
+        asm volatile("" : "+v"(d));
+        const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7;
+        const int py = q.py0 + oyt, px = q.px0 + oxt;
+        const int ch = cblk + slot * 8;
+        half8 v = ov[it];
+        if (use_res) v = v + rr[it];                     // fp16 add, round-to-nearest-even = the wrapper's add
+        if (a.relu) {                                    // x > 0 ? x : +0, on the sign bits
+          short8 b = __builtin_bit_cast(short8, v);
+          b = b & ~(b >> 15);
+          v = __builtin_bit_cast(half8, b);
+        }
+        if (d >= 0 && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
           const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
-          const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
-          half8 v = *reinterpret_cast<const half8*>(obuf + pw * ROWB + slot * 16);
-          if (a.res != nullptr) v = v + rres[it];          // fp16 add, round-to-nearest-even = the wrapper's add
-          if (a.relu) {                                    // x > 0 ? x : +0, on the sign bits
-            short8 b = __builtin_bit_cast(short8, v);
-            b = b & ~(b >> 15);
-            v = __builtin_bit_cast(half8, b);
-          }
+          const size_t pix = ((size_t)q.n * a.H_full + oy) * a.W_full + ox;
           *reinterpret_cast<half8*>(a.y + pix * a.out_ld + ch) = v;
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic on the buffer is over
-      SSTAMP(e3);
-#ifdef RTPE_CONV_STAMPS
-      s_ewait += e1 - e0; s_etr += e2 - e1; s_est += e3 - e2;
-#endif
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS traffic on the buffer is over
+    if (use_res && u + 2 < n_units) load_res(u + 2, rr);   // this register set is free again
     bsel = bsel + 1 == NB ? 0 : bsel + 1;
-    wsel = wsel == 0 ? 2 : wsel - 1;                     // (2 (s+1)) % 3 = (wsel + 2) % 3
-    SSTAMP(c5);
+    wsel = wsel == 0 ? 2 : wsel - 1;
+  };
+
+  half8 rres_a[NIT], rres_b[NIT];
+  if (use_res) {
+    load_res(0, rres_a);
+    if (n_units > 1) load_res(1, rres_b);
   }
-#ifdef RTPE_CONV_STAMPS
-  if (a.dbg != nullptr && lane == 0) {
-    atomicAdd(&a.dbg[0], s_waitm); atomicAdd(&a.dbg[1], s_h0); atomicAdd(&a.dbg[2], s_waith);
-    atomicAdd(&a.dbg[3], s_h1); atomicAdd(&a.dbg[4], s_other); atomicAdd(&a.dbg[5], (unsigned long long)S);
-    atomicAdd(&a.dbg[12], s_ewait); atomicAdd(&a.dbg[13], s_etr); atomicAdd(&a.dbg[14], s_est);
+  for (int u = 0; u < n_units; u += 2) {
+    run_unit(u, rres_a);
+    if (u + 1 < n_units) run_unit(u + 1, rres_b);
   }
-#endif
 }
 
 template <int MT, int NT, int WAVES>

@@ -80,6 +80,7 @@ struct ConvArgs {
   int buf_bytes;         // persistent / streaming kernel: bytes of one LDS tile buffer
   int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
   int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
+  int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
   unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
 
