@@ -145,6 +145,34 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   const int total = a.halo_h * rowslots;
   const T* xin = reinterpret_cast<const T*>(a.x) + (size_t)n * a.H_in * a.W_in * a.in_ld;
 
+  // residual row pieces of this workgroup's tile (the same (pixel, 16-byte slot) walk as the store
+  // loop of the epilogue).  All of them are requested together, and as early as the register budget
+  // allows, so that one memory round trip is paid per tile instead of one per row piece.
+  constexpr int CHG = MT * 16 / EPS;                    // 16-byte chunks per pixel row
+  constexpr int NITG = (NT * 16 * CHG + 63) / 64;
+  constexpr bool kEarlyRes = NITG <= 4;                 // 16 VGPRs: small tiles only, the others keep their occupancy
+  uint4 rpre[kEarlyRes ? NITG : 1];
+  auto issue_res = [&]() {
+    const T* rin = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int it = 0; it < (kEarlyRes ? NITG : 0); ++it) {
+      const int c = it * 64 + lane;
+      const int pw = c / CHG, slot = c - pw * CHG;
+      const uint32_t p = wv * NT * 16 + pw;
+      const uint32_t oyt = fdiv(p, a.div_tw);
+      const uint32_t oxt = p - oyt * a.tw;
+      const int py = py0 + (int)oyt, px = px0 + (int)oxt;
+      const int ch = cb * MT * 16 + slot * EPS;
+      rpre[it] = uint4{0u, 0u, 0u, 0u};
+      if (c < NT * 16 * CHG && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
+        const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+        const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
+        rpre[it] = *reinterpret_cast<const uint4*>(rin + pix * a.res_ld + ch);
+      }
+    }
+  };
+  if (kEarlyRes && a.res != nullptr) issue_res();
+
   int kf = 0;  // linear k-chunk index over (channel chunk, k chunk)
   RTPE_STAMP(1);
   for (int cci = 0; cci < a.n_cchunks; ++cci) {
@@ -283,7 +311,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       T v[EPS];
       __builtin_memcpy(v, &raw, 16);
       if (rin != nullptr) {
-        const uint4 rraw = *reinterpret_cast<const uint4*>(rin + pix * a.res_ld + ch);
+        uint4 rraw;
+        if constexpr (kEarlyRes) rraw = rpre[it];
+        else rraw = *reinterpret_cast<const uint4*>(rin + pix * a.res_ld + ch);
         T rr[EPS];
         __builtin_memcpy(rr, &rraw, 16);
 #pragma unroll
