@@ -36,8 +36,8 @@ MFMA_PEAK_TFS = 2500.0       # dense fp16/bf16 MFMA
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--weights", default="W0", choices=["W0", "W1"])
@@ -61,6 +61,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+
+    # host thread pools: the box gives one GPU a CPU quota (cgroup); hundreds of idle-spinning OpenMP
+    # threads (torch defaults to one per visible core) exhaust it and the kernel launches stall
+    host_threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8, 8))
+    torch.set_num_threads(host_threads)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -91,12 +96,15 @@ def main():
     op_ms = np.zeros(n_ops)
     people = [0]
 
-    n_slots = 8
+    n_slots = 4
+    for slot in range(n_slots):          # creates the per-op events of every record slot outside the timed region
+        eng.forward_record(x, slot)
 
     def run_steps(k_steps, record):
         """k_steps pipelined steps: forward(k+1) is enqueued before decode(k)'s host work"""
         def fwd(k, xb):
-            return eng.forward_record(xb, k % n_slots) if record else eng.forward(xb)
+            # per-op events for the first n_slots timed steps only (their markers cost launch gaps)
+            return eng.forward_record(xb, k) if record and k < n_slots else eng.forward(xb)
         last = None
         for res in pipe.stream((x for _ in range(k_steps)), (S, S), on_forward=fwd):
             people[0] = sum(len(p) if p.ndim == 3 else 0 for p, _ in res)

@@ -105,32 +105,36 @@ class TeacherPipeline:
         return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
 
     def stream(self, batches, out_hw=None, on_forward=None):
-        """Software-pipelined loop over an iterable of (N,3,H,W) GPU batches: the forward
-        of batch k+1 is enqueued before the host part of batch k's decode (top-k read-back,
-        C++ matching, refine read-back) runs, and the decode kernels go to a side stream,
-        so the two overlap.  Yields one ``[(people, scores)] * N`` list per batch, in order.
-        ``on_forward(k, x)`` may replace the plain forward (bench.py records op events)."""
-        side = torch.cuda.Stream(device=self.device)
-        main = torch.cuda.current_stream(self.device)
-        pending = None
-
-        def decode(item):
-            (preds, refined), done, hw = item
-            with torch.cuda.stream(side):
-                side.wait_event(done)
-                return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
-
+        """Software-pipelined loop over an iterable of (N,3,H,W) GPU batches.  Everything goes to
+        ONE stream, in the order  F(k) R(k-1) T(k)  (forward, adjust+refine of the previous batch,
+        fused top-k): the network kernels fill the chip, so decode kernels on a side stream only
+        ran once the forward queue was empty.  The host part of the decode of batch k-1 (tag
+        matching on the host cores) runs while the GPU executes F(k), whose launches are already
+        queued; the GPU never waits for the host.  The decode tables travel through pinned host
+        memory that the kernels read and write in place (no copy commands in the stream).
+        Yields one ``[(people, scores)] * N`` list per batch, in order, two steps after the batch
+        was submitted.  ``on_forward(k, x)`` may replace the plain forward (bench.py records op
+        events).  Keep the host thread pools small (``torch.set_num_threads``): a burst of idle-
+        spinning OpenMP threads can exhaust a container's CPU quota and stall the launches."""
+        topk_done = None      # batch k-1: top-k enqueued
+        refine_done = None    # batch k-2: refine enqueued
+        P = self.parser
         with torch.no_grad():
             for k, x in enumerate(batches):
-                out = on_forward(k, x) if on_forward is not None else self.model(x)
-                done = torch.cuda.Event()
-                done.record(main)
+                preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
                 hw = tuple(out_hw) if out_hw is not None else tuple(x.shape[2:])
-                if pending is not None:
-                    yield decode(pending)
-                pending = (out, done, hw)
-            if pending is not None:
-                yield decode(pending)
+                if topk_done is not None:
+                    P.lowres_match(topk_done)          # host matching overlaps F(k) on the GPU
+                st = P.lowres_topk(refined, preds[:, NUM_HEATMAPS:], hw)
+                if refine_done is not None:
+                    yield P.lowres_finish(refine_done)
+                refine_done, topk_done = topk_done, st
+            if topk_done is not None:
+                P.lowres_match(topk_done)
+            if refine_done is not None:
+                yield P.lowres_finish(refine_done)
+            if topk_done is not None:
+                yield P.lowres_finish(topk_done)
 
     def gather(self, image_ids, results):
         """all-gather of the decoded keypoints over the process group (RCCL)"""
