@@ -182,9 +182,8 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
 
 /* kernel variant of conv op i for (N,H,W): out8 = {cout tiles/wave, pixel
  * tiles/wave, waves, tile_h, tile_w, channel chunk, cout blocks, v} with
- * v > 0: LDS bytes of the one-workgroup-per-tile kernel; -100000 < v < 0: -(workgroups)
- * of the persistent kernel; v <= -100000: -(workgroups + 100000 * halo buffers) of the
- * streaming kernel */
+ * v > 0: LDS bytes of the one-workgroup-per-tile kernel; v <= -100000:
+ * -(workgroups + 100000 * halo buffers) of the streaming kernel */
 int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8);
 
 /* ------------------------------------------------------------------------ *

@@ -443,57 +443,6 @@ static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
   return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
 }
 
-// persistent kernel (conv_persist.hip): two LDS tile buffers + a loader wave
-static ConvTile make_persist_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
-  static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
-  static const int force_waves = getenv("RTPE_CONV_WAVES") ? atoi(getenv("RTPE_CONV_WAVES")) : 0;
-  static const int force_wgs = getenv("RTPE_CONV_WGS_PER_CU") ? atoi(getenv("RTPE_CONV_WGS_PER_CU")) : 0;
-  double best_score = 1e30;
-  ConvTile best;
-  memset(&best, 0, sizeof(best));
-  for (const TileCand& c : kCands) {
-    if (p.mt == 4 && c.nt == 8) continue;
-    if (c.nt == 8 && !force_nt) continue;            // residual prefetch + 96 accumulators would not fit 2 waves/SIMD
-    if (force_nt && c.nt != force_nt) continue;
-    if (force_waves && c.waves != force_waves) continue;
-    const int hh = (c.th - 1) * p.in_mul + p.tapw, hw = (c.tw - 1) * p.in_mul + p.tapw;
-    size_t in_tile = (size_t)hh * hw * p.pstride;
-    const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
-    size_t buf = in_tile > out_tile ? in_tile : out_tile;
-    buf = (buf + 1023) / 1024 * 1024;
-    const size_t lds = kTapTableBytes + 2 * buf;
-    if (lds > 160 * 1024) continue;
-    int wgs_cu = (int)(160 * 1024 / lds);
-    const int by_waves = 12 / (c.waves + 1);         // <= 168 VGPRs -> 3 waves per SIMD = 12 per CU
-    if (wgs_cu > by_waves) wgs_cu = by_waves;
-    if (wgs_cu > 3) wgs_cu = 3;
-    if (force_wgs && wgs_cu > force_wgs) wgs_cu = force_wgs;
-    const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
-    const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
-                         ((double)H_pos * W_pos);
-    const long units = tiles * p.n_cb;
-    // workgroups: a multiple of 8 (XCDs), per-XCD count a multiple of n_cb
-    long G = 256L * wgs_cu / 8;
-    const long need = (units + 7) / 8;
-    if (G > need) G = need;
-    G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
-    const double rounds = (double)units / (8.0 * G);  // units per workgroup
-    const double imbalance = (double)((long)(rounds + 0.999)) / rounds;
-    double score = waste * imbalance;
-    const double conc_waves = (double)(8 * G) * c.waves / 256.0;   // MFMA waves per CU
-    if (conc_waves < 8) score *= 1.0 + 0.05 * (8 - conc_waves);
-    score *= 1.0 + 0.15 / c.nt;
-    const double halo = (double)hh * hw / ((double)c.th * c.tw * p.in_mul * p.in_mul);
-    score *= 1.0 + 0.15 * (halo - 1.0);
-    if (score < best_score) {
-      best_score = score;
-      best.nt = c.nt; best.waves = c.waves; best.th = c.th; best.tw = c.tw;
-      best.lds_bytes = lds; best.kind = 1; best.grid = (int)(8 * G); best.buf_bytes = (int)buf;
-    }
-  }
-  return best;
-}
-
 // streaming kernel (conv_stream.hip): one workgroup per CU, 3-slot weight ring + 2-3 halo buffers
 static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, ConvTile* out) {
   if (!conv_stream_supports(p) || (c.nt != 4 && c.nt != 5) || c.tw > 40) return false;
@@ -550,11 +499,6 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
   if (stream && conv_stream_supports(p)) {
     ConvTile t = make_stream_tile(p, N, H_pos, W_pos);
-    if (t.nt) return t;
-  }
-  static const int persist = getenv("RTPE_CONV_PERSIST") ? atoi(getenv("RTPE_CONV_PERSIST")) : 1;
-  if (persist && p.esize == 2 && p.dil == 1 && p.cc == 48 && p.pstride == 96) {
-    ConvTile t = make_persist_tile(p, N, H_pos, W_pos);
     if (t.nt) return t;
   }
   static const long lds_cap = getenv("RTPE_CONV_LDS_CAP") ? atol(getenv("RTPE_CONV_LDS_CAP")) : 80 * 1024;
@@ -659,25 +603,6 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
       ConvTile st;
       if (stream_tile(p, c, N, H_pos, W_pos, &st)) out->push_back(st);   // streaming, LDS-DMA operands
     }
-    if (p.esize == 2 && p.dil == 1 && p.cc == 48 && p.pstride == 96 && c.nt <= 5) {   // persistent + loader wave
-      size_t buf = in_tile > out_tile ? in_tile : out_tile;
-      buf = (buf + 1023) / 1024 * 1024;
-      const size_t lds = kTapTableBytes + 2 * buf;
-      if (lds > 160 * 1024) continue;
-      int max_wgs = (int)(160 * 1024 / lds);
-      if (max_wgs > 12 / (c.waves + 1)) max_wgs = 12 / (c.waves + 1);
-      const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
-      const long units = tiles * p.n_cb;
-      for (int wgs = 1; wgs <= max_wgs; ++wgs) {
-        long G = 256L * wgs / 8;
-        const long need = (units + 7) / 8;
-        if (G > need) G = need;
-        G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
-        ConvTile q = t;
-        q.kind = 1; q.lds_bytes = lds; q.grid = (int)(8 * G); q.buf_bytes = (int)buf;
-        out->push_back(q);
-      }
-    }
   }
 }
 
@@ -696,7 +621,6 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
                "(in_ld=%d out_ld=%d cout_store=%d y=%p)", eps, a.in_ld, a.out_ld, a.cout_store, (void*)a.y);
   RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
-  if (t.kind == 1) return conv_persist_launch(p, t, a, s);
   if (t.kind == 2) return conv_stream_launch(p, t, a, s);
 #define RTPE_V(MTv, NTv, Wv)                                                                  \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv)                                            \

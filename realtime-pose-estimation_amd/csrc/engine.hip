@@ -513,7 +513,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     if (it != h->tuned.end() && it->second[op * 4].nt) t = it->second[op * 4];
   }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 1 ? -t.grid : (int32_t)t.lds_bytes;
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : (int32_t)t.lds_bytes;
   return RTPE_OK;
 }
 
@@ -573,7 +573,7 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
     }
     h->tuned[shape] = trial;
     std::vector<float> best_ms(n_ops, 1e30f);
-    for (int rep = 0; rep < 3; ++rep) {           // first repetition also warms caches for this choice
+    for (int rep = 0; rep < 4; ++rep) {           // first repetition also warms caches for this choice
       rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
       if (rc != RTPE_OK) { h->tuned.erase(shape); return rc; }
       if (rep == 0) continue;

@@ -77,7 +77,7 @@ struct ConvArgs {
   FastDiv div_tw, div_slots, div_rowslots, div_cc, div_tiles_x, div_tiles_xy;
   size_t x_bytes;        // bytes from x to the end of its tensor (buffer bounds of the LDS-DMA path)
   int n_cb;              // cout blocks
-  int buf_bytes;         // persistent / streaming kernel: bytes of one LDS tile buffer
+  int buf_bytes;         // streaming kernel: bytes of one LDS tile buffer
   int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
   int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
@@ -97,10 +97,10 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int nt, waves;        // pixel tiles (x16) per wave, MFMA waves per workgroup
   int th, tw;
   size_t lds_bytes;
-  int kind;             // 0: one workgroup per tile (conv_mfma.hip), 1: persistent + loader wave (conv_persist.hip),
-                        // 2: streaming, weights and halos by LDS-DMA (conv_stream.hip)
-  int grid;             // persistent / streaming: number of workgroups
-  int buf_bytes;        // persistent / streaming: one LDS tile buffer
+  int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
+                        // (conv_stream.hip)
+  int grid;             // streaming: number of workgroups
+  int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
   int n_wslots;         // streaming: weight half-stage slots
 };
@@ -121,7 +121,6 @@ void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w, void
 // fill geometry / divisors of `a` (pointers, sizes and flags are the caller's)
 void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, ConvArgs* a);
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
-int conv_persist_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 bool conv_stream_supports(const ConvPlan& p);
 size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots);
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);

@@ -27,6 +27,7 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--last-forwards", type=int, default=0)
+    ap.add_argument("--drop-last", type=int, default=0, help="ignore the last N forward passes (bench.py's forward-only tail)")
     ap.add_argument("--csv", default=None)
     ap.add_argument("paths", nargs="*", default=["gpurun_out/**/*kernel_trace.csv"])
     a = ap.parse_args()
@@ -38,7 +39,9 @@ def main():
                 stems = [int(r["Start_Timestamp"]) for r in rows if "stem_kernel" in r["Kernel_Name"]]
                 if len(stems) >= a.last_forwards:
                     t0 = stems[-a.last_forwards]
-                    rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+                    t1 = stems[-a.drop_last] if a.drop_last else None
+                    rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0 and
+                            (t1 is None or int(r["Start_Timestamp"]) < t1)]
             agg = collections.OrderedDict()
             for r in rows:
                 key = (short(r["Kernel_Name"]), r["Workgroup_Size_X"], r["VGPR_Count"])
@@ -46,12 +49,12 @@ def main():
             total = sum(sum(v) for v in agg.values())
             span = (max(int(r["End_Timestamp"]) for r in rows) - min(int(r["Start_Timestamp"]) for r in rows)) / 1e3
             print("== %s: %d dispatches, kernel time %.1f us over a span of %.1f us" % (path, len(rows), total, span))
-            out = [("kernel", "workgroup", "vgpr", "calls", "total_us", "mean_us", "min_us", "pct")]
+            out = [("kernel", "workgroup", "vgpr", "calls", "total_us", "mean_us", "median_us", "min_us", "pct")]
             for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-                out.append(k + (len(v), round(sum(v), 1), round(sum(v) / len(v), 2), round(min(v), 2),
+                out.append(k + (len(v), round(sum(v), 1), round(sum(v) / len(v), 2), round(sorted(v)[len(v) // 2], 2), round(min(v), 2),
                                 round(100 * sum(v) / total, 2)))
             for o in out[:40]:
-                print("%-60s wg %5s vgpr %5s n=%-5s total %11s mean %9s min %9s %6s" % o)
+                print("%-60s wg %5s vgpr %5s n=%-5s total %11s mean %9s median %9s min %9s %6s" % o)
             if a.csv:
                 with open(a.csv, "w") as f:
                     for o in out:
