@@ -108,7 +108,7 @@ def main():
         last = None
         for res in pipe.stream((x for _ in range(k_steps)), (S, S), on_forward=fwd):
             people[0] = sum(len(p) if p.ndim == 3 else 0 for p, _ in res)
-            last = pipe.gather(ids, res)
+            last = pipe.gather(ids, res, equal_counts=True)
         return last
 
     def fence():

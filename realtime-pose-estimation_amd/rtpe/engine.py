@@ -61,10 +61,27 @@ def eval_student(model, hm_parser, val_dataloader, device,
     return OrderedDict(images=len(all_preds), people=sum(len(p) for p in all_preds))
 
 
+_PIN_RING = {}
+
+
 def pack_records(image_ids, results, device):
     """fixed-size keypoint records for the all-gather: per image
-    ``[image_index, n_people, scores[30], kpts[30][17][4]]`` as float32"""
-    rec = np.zeros((len(results), RECORD_FLOATS), np.float32)
+    ``[image_index, n_people, scores[30], kpts[30][17][4]]`` as float32.  On a GPU the records go
+    through a small ring of pinned host buffers and an asynchronous copy, so packing never waits
+    for the kernels queued on the stream."""
+    device = torch.device(device)
+    n_img = len(results)
+    if device.type == "cuda":
+        ring = _PIN_RING.setdefault(n_img, {"i": 0, "bufs": []})
+        if len(ring["bufs"]) < 4:
+            ring["bufs"].append(torch.zeros((n_img, RECORD_FLOATS), dtype=torch.float32, pin_memory=True))
+        host = ring["bufs"][ring["i"] % len(ring["bufs"])]
+        ring["i"] += 1
+        host.zero_()
+        rec = host.numpy()
+    else:
+        host = None
+        rec = np.zeros((n_img, RECORD_FLOATS), np.float32)
     for i, (img_id, (people, scores)) in enumerate(zip(image_ids, results)):
         n = min(len(people) if people.ndim == 3 else 0, MAX_PEOPLE_RECORD)
         rec[i, 0], rec[i, 1] = img_id, n
@@ -72,6 +89,8 @@ def pack_records(image_ids, results, device):
             rec[i, 2:2 + n] = np.asarray(scores[:n], np.float32)
             rec[i, 2 + MAX_PEOPLE_RECORD:2 + MAX_PEOPLE_RECORD + n * NUM_HEATMAPS * 4] = \
                 people[:n, :, :4].reshape(-1)
+    if host is not None:
+        return host.to(device, non_blocking=True)
     return torch.from_numpy(rec).to(device)
 
 
@@ -136,19 +155,26 @@ class TeacherPipeline:
             if topk_done is not None:
                 yield P.lowres_finish(topk_done)
 
-    def gather(self, image_ids, results):
-        """all-gather of the decoded keypoints over the process group (RCCL)"""
+    def gather(self, image_ids, results, equal_counts=False):
+        """all-gather of the decoded keypoints over the process group (RCCL).  ``equal_counts``:
+        every rank contributes the same number of images (no count exchange, no host sync)."""
         import torch.distributed as dist
         rec = pack_records(image_ids, results, self.device)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return rec
-        return all_gather_records(rec)
+        return all_gather_records(rec, equal_counts)
 
 
-def all_gather_records(rec):
-    """variable count per rank: pad to the max, gather, strip the padding"""
+def all_gather_records(rec, equal_counts=False):
+    """records of all ranks, in rank order.  Variable count per rank: pad to the max, gather,
+    strip the padding (one count exchange that the host has to read); with ``equal_counts`` a
+    single collective and nothing for the host to wait for."""
     import torch.distributed as dist
     world = dist.get_world_size()
+    if equal_counts:
+        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec.contiguous())
+        return out
     n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)

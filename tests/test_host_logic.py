@@ -166,6 +166,11 @@ def _gloo_worker(rank, world, port, q):
           "n": torch.tensor(5 if rank == 0 else 0)}
     sd = engine.broadcast_state_dict(sd, 0, "cpu")
     out = engine.unpack_records(allrec)
+    # equal shards (what bench.py runs): one collective, no count exchange
+    ids2 = [rank * 2, rank * 2 + 1]
+    rec2 = engine.pack_records(ids2, [(np.full((1, 17, 4), float(i), np.float32), [float(i)]) for i in ids2], "cpu")
+    out2 = engine.unpack_records(engine.all_gather_records(rec2, equal_counts=True))
+    assert sorted(out2) == [0, 1, 2, 3] and all(float(out2[i][1][0]) == float(i) for i in out2)
     q.put((rank, sorted(out.keys()), [float(out[i][0][0, 0, 0]) for i in sorted(out)],
            sd["a"].tolist(), sd["b"].tolist(), int(sd["n"])))
     dist.destroy_process_group()
