@@ -211,6 +211,18 @@ int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t W, int32_t 
  * Decode: validate_hhrnet.py:94-98 + rtpe/third_party/group.py:125-287.
  * ------------------------------------------------------------------------ */
 
+/* Pre-processing in front of the path: cv2.warpAffine of
+ * resize_align_multi_scale (rtpe/third_party/transforms.py:181-192, matrix of
+ * get_affine_transform :59-93) + torchvision ToTensor + Normalize
+ * (validate_hhrnet.py:63-67) in one pass.  src: (h, w, 3) uint8 on the device, row
+ * stride in bytes; m_dst_to_src: the 2x3 matrix that maps destination pixel (x, y)
+ * to source coordinates (the inverse of what warpAffine is given); dst: (3, oh, ow)
+ * fp32.  Bilinear weights in fp32, zero outside the image (documented convention:
+ * cv2's fixed-point interpolation is not pinned).  Stream-ordered. */
+int rtpe_warp_normalize(const void* src_hwc_u8, int32_t h, int32_t w, int32_t stride_bytes,
+                        const float* m_dst_to_src, const float* mean, const float* stdev,
+                        void* dst_chw_f32, int32_t oh, int32_t ow, void* stream);
+
 /* F.interpolate(mode="bilinear", align_corners=True), fp32 NCHW planes.
  * validate_hhrnet.py:94-98.  src (planes,h,w) -> dst (planes,oh,ow). */
 int rtpe_bilinear_upsample(const float* src, int32_t planes, int32_t h, int32_t w,

@@ -573,7 +573,7 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
     }
     h->tuned[shape] = trial;
     std::vector<float> best_ms(n_ops, 1e30f);
-    for (int rep = 0; rep < 4; ++rep) {           // first repetition also warms caches for this choice
+    for (int rep = 0; rep < 6; ++rep) {           // first repetition also warms caches for this choice
       rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
       if (rc != RTPE_OK) { h->tuned.erase(shape); return rc; }
       if (rep == 0) continue;

@@ -187,6 +187,76 @@ def all_gather_records(rec, equal_counts=False):
     return torch.cat(keep)
 
 
+# --------------------------------------------------------------------------- #
+# teacher-prediction files (teacher_inference.py:67-90 writes them, dataloaders.py:140-165 reads them)
+# --------------------------------------------------------------------------- #
+HEATMAPS_ORDER = ["nose", "leye", "reye", "lear", "rear", "lshould", "rshould", "lelbow", "relbow", "lwrist",
+                  "rwrist", "lhip", "rhip", "lknee", "rknee", "lankle", "rankle"]   # teacher_inference.py:38-40
+
+
+def teacher_prediction_path(out_dir, img_path):
+    """teacher_inference.py:68-69; numpy appends ``.npz``, the reader asks for
+    ``<img_id>.jpg_w48_predictions.npz`` (dataloaders.py:149-150)"""
+    import os
+    return os.path.join(out_dir, os.path.basename(img_path)) + "_w48_predictions"
+
+
+def save_teacher_predictions(out_path, preds, refined):
+    """teacher_inference.py:83-90: ``preds`` (34,h,w) and ``refined`` (17,2h,2w) of ONE image (tensors or
+    arrays, a leading batch axis of 1 is squeezed) -> compressed npz with the reference's four keys"""
+    preds = np.asarray(preds.detach().cpu() if torch.is_tensor(preds) else preds, np.float32).squeeze()
+    refined = np.asarray(refined.detach().cpu() if torch.is_tensor(refined) else refined, np.float32).squeeze()
+    if preds.ndim != 3 or preds.shape[0] != 2 * NUM_HEATMAPS or refined.ndim != 3 or refined.shape[0] != NUM_HEATMAPS:
+        raise ValueError("save_teacher_predictions: expected (34,h,w) and (17,H,W), got %s and %s"
+                         % (preds.shape, refined.shape))
+    np.savez_compressed(out_path, pred_heatmaps=preds[:NUM_HEATMAPS], embeddings=preds[NUM_HEATMAPS:],
+                        heatmaps_refined=refined, heatmaps_order=HEATMAPS_ORDER)
+
+
+def load_teacher_predictions(path, out_hw=None, device=None):
+    """dataloaders.py:140-165 ``_get_teacher_data``: -> ``(t_hms, t_ae)`` float32 tensors
+    ``heatmaps_refined`` (17,H,W) and ``embeddings`` (17,h,w); with ``out_hw`` both are upsampled with
+    ``F.interpolate(mode="bilinear", align_corners=True)`` semantics on the GPU (``device`` required)."""
+    npz = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+    t_hms = torch.from_numpy(np.ascontiguousarray(npz["heatmaps_refined"], np.float32))
+    t_ae = torch.from_numpy(np.ascontiguousarray(npz["embeddings"], np.float32))
+    if device is not None:
+        t_hms, t_ae = t_hms.to(device), t_ae.to(device)
+    if out_hw is not None:
+        from .third_party.group import upsample_bilinear
+        t_hms = upsample_bilinear(t_hms.unsqueeze(0), out_hw)[0]
+        t_ae = upsample_bilinear(t_ae.unsqueeze(0), out_hw)[0]
+    return t_hms, t_ae
+
+
+def export_teacher_predictions(model, items, out_dir, workers=4):
+    """teacher_inference.py:67-90 as a loop: ``items`` yields ``(img_path, t)`` with ``t`` (1,3,H,W) on
+    the GPU (see ``rtpe.third_party.transforms.warp_normalize``).  The forward of the next image is
+    enqueued while a small thread pool compresses and writes the previous ones (the ~3 MB of
+    deflate per image is the cost of this path).  Returns the list of files written."""
+    from concurrent.futures import ThreadPoolExecutor
+    written, futures = [], []
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as pool, torch.no_grad():
+        for img_path, t in items:
+            preds, refined = model(t)
+            out_path = teacher_prediction_path(out_dir, img_path)
+            p_host = torch.empty(preds.shape, dtype=torch.float32, pin_memory=True)
+            r_host = torch.empty(refined.shape, dtype=torch.float32, pin_memory=True)
+            p_host.copy_(preds, non_blocking=True)
+            r_host.copy_(refined, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+
+            def job(ev=ev, p=p_host, r=r_host, path=out_path):
+                ev.synchronize()
+                save_teacher_predictions(path, p.numpy(), r.numpy())
+                return path + ".npz"
+            futures.append(pool.submit(job))
+        for f in futures:
+            written.append(f.result())
+    return written
+
+
 def shard_indices(n_items, rank, world):
     """contiguous blocks, sizes differing by at most one (100 images over 8 ranks
     -> 13,13,13,13,12,12,12,12)"""

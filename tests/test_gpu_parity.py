@@ -427,3 +427,53 @@ def test_student_vs_golden_and_oracle(nat, golden_dir):
     ed = (det2.cpu() - od).abs().max().item()
     print("student vs oracle 192x256: att %.3e det %.3e" % (ea, ed))
     assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
+
+
+# --------------------------------------------------------------------------- #
+# row 8f-1: pre-processing (warp + ToTensor + Normalize)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("hw", [(480, 640), (555, 640), (640, 427), (97, 131)])
+def test_warp_normalize_vs_oracle(nat, hw):
+    """the GPU warp against the numpy restatement of the same convention (cv2 itself is unpinned)"""
+    from oracle import preprocess_ref
+    from rtpe.third_party import transforms
+    rng = np.random.default_rng(hw[0])
+    img = rng.integers(0, 256, size=hw + (3,), dtype=np.uint8)
+    want, center, scale = preprocess_ref.warp_normalize(img, 640, transforms.IMAGENET_MEAN, transforms.IMAGENET_STD)
+    got, c2, s2 = transforms.warp_normalize(img, 640, device="cuda:0")
+    assert got.shape == (1,) + want.shape and got.shape[2] % 64 == 0 and got.shape[3] % 64 == 0
+    np.testing.assert_array_equal(center, c2)
+    err = np.abs(got[0].cpu().numpy() - want).max()
+    # the two 2x3 matrices (3-point solve vs closed form) agree to 1e-9 but may round differently to fp32,
+    # which moves a sampling position by one ulp; one grey level would be 1.7e-2
+    assert err <= 2e-4, err
+    u8, _, _ = transforms.resize_align_multi_scale(img, 640, 1, 1, device="cuda:0")
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (got.shape[2], got.shape[3], 3)
+    # feeding the teacher: the result is a valid network input (H, W multiples of 32)
+    assert got.shape[2] % 32 == 0 and got.shape[3] % 32 == 0
+
+
+def test_teacher_prediction_export_and_reader(nat, teacher, tmp_path):
+    """row 8f-2 end to end: warp -> teacher -> npz -> reader with out_hw (bit-equal to the CPU interpolate)"""
+    from rtpe import engine
+    from rtpe.third_party import transforms
+    model, sd = teacher("W0")
+    rng = np.random.default_rng(3)
+    names = ["a.jpg", "b.jpg"]
+    items = []
+    for nm in names:
+        img = rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)
+        t, _, _ = transforms.warp_normalize(img, 128, device="cuda:0")
+        items.append((os.path.join("/somewhere", nm), t))
+    files = engine.export_teacher_predictions(model, items, str(tmp_path), workers=2)
+    assert [os.path.basename(f) for f in files] == [n + "_w48_predictions.npz" for n in names]
+    with torch.no_grad():
+        preds, refined = model(items[1][1])
+    npz = np.load(files[1])
+    np.testing.assert_array_equal(npz["heatmaps_refined"], refined[0].cpu().numpy())
+    np.testing.assert_array_equal(npz["embeddings"], preds[0, 17:].cpu().numpy())
+    hw = (items[1][1].shape[2], items[1][1].shape[3])
+    t_hms, t_ae = engine.load_teacher_predictions(files[1], out_hw=hw, device="cuda:0")
+    want = F.interpolate(refined[:1].cpu(), hw, mode="bilinear", align_corners=True)[0]
+    assert torch.equal(t_hms.cpu(), want)
+    assert tuple(t_ae.shape) == (17,) + hw

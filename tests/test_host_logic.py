@@ -219,3 +219,50 @@ def test_student_state_dict_and_program(built, golden_dir):
         before = stu.att_top[0].bias.clone()
         stu.load_state_dicts(pre)
         assert torch.equal(stu.att_top[0].bias, before + 1)
+
+
+def test_preprocess_geometry(built):
+    """row 8f-1: output size / centre / scale of resize_align_multi_scale (transforms.py:155-176) for the
+    shapes SURVEY 0.5 works out by hand, product == oracle restatement, and the inverse map"""
+    from oracle import preprocess_ref
+    from rtpe.third_party import transforms
+    for (h, w), want in (((480, 640), (896, 640)), ((555, 640), (768, 640)), ((640, 480), (640, 896)),
+                         ((427, 640), (960, 640)), ((640, 640), (640, 640))):
+        img = np.zeros((h, w, 3), np.uint8)
+        size, center, scale = transforms.get_multi_scale_size(img, 640, 1, 1)
+        size2, center2, scale2 = preprocess_ref.multi_scale_size(h, w, 640)
+        assert size == want == size2
+        np.testing.assert_array_equal(center, center2)
+        np.testing.assert_allclose(scale, scale2, rtol=0, atol=0)
+        m = transforms.get_affine_transform(center, scale, 0, size, inv=1)
+        np.testing.assert_allclose(m, preprocess_ref.dst_to_src_matrix(center, scale, size), atol=1e-9)
+        fwd = transforms.get_affine_transform(center, scale, 0, size)
+        p = transforms.affine_transform(transforms.affine_transform([10., 20.], fwd), m)
+        np.testing.assert_allclose(p, [10., 20.], atol=1e-9)
+    # keypoints back to image coordinates (get_final_preds :195-202)
+    size, center, scale = transforms.get_multi_scale_size(np.zeros((480, 640, 3), np.uint8), 640, 1, 1)
+    person = np.array([[448., 320., 0.9, 1.0]])
+    back = transforms.get_final_preds([[person]], center, scale, size)[0]
+    np.testing.assert_allclose(back[0, :2], center, atol=1e-6)      # the centre of the warped image maps to the centre
+
+
+def test_teacher_prediction_files(built, tmp_path):
+    """row 8f-2: the npz schema of teacher_inference.py:86-90 and what dataloaders.py:149-154 reads back"""
+    from rtpe import engine
+    rng = np.random.default_rng(0)
+    preds = rng.standard_normal((1, 34, 40, 56)).astype(np.float32)
+    refined = rng.standard_normal((1, 17, 80, 112)).astype(np.float32)
+    base = engine.teacher_prediction_path(str(tmp_path), "/data/coco/000000000139.jpg")
+    assert base.endswith("000000000139.jpg_w48_predictions")
+    engine.save_teacher_predictions(base, torch.from_numpy(preds), refined)
+    npz = np.load(base + ".npz")
+    assert sorted(npz.files) == ["embeddings", "heatmaps_order", "heatmaps_refined", "pred_heatmaps"]
+    np.testing.assert_array_equal(npz["pred_heatmaps"], preds[0, :17])
+    np.testing.assert_array_equal(npz["embeddings"], preds[0, 17:])
+    np.testing.assert_array_equal(npz["heatmaps_refined"], refined[0])
+    assert list(npz["heatmaps_order"]) == engine.HEATMAPS_ORDER and npz["heatmaps_order"].dtype.kind == "U"
+    t_hms, t_ae = engine.load_teacher_predictions(base)
+    assert t_hms.dtype == torch.float32 and tuple(t_hms.shape) == (17, 80, 112) and tuple(t_ae.shape) == (17, 40, 56)
+    np.testing.assert_array_equal(t_ae.numpy(), preds[0, 17:])
+    with pytest.raises(ValueError):
+        engine.save_teacher_predictions(base, preds[:, :30], refined)
