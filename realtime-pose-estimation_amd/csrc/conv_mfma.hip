@@ -444,7 +444,8 @@ static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
 }
 
 // streaming kernel (conv_stream.hip): one workgroup per CU, 3-slot weight ring + 2-3 halo buffers
-static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, ConvTile* out) {
+static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, ConvTile* out,
+                        bool allow_resident = true) {
   if (!conv_stream_supports(p) || (c.nt != 4 && c.nt != 5) || c.tw > 40) return false;
   const int hh = c.th + 2, hw = c.tw + 2;
   const size_t in_tile = (size_t)hh * hw * p.pstride;
@@ -453,7 +454,8 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   buf = (buf + 255) / 256 * 256;
   // weights resident (loaded once per workgroup) when all halves of a cout block fit beside 2 halo buffers
   int nw = 3, nb = 3;
-  if (p.n_cchunks <= 2 && conv_stream_lds(p, (int)buf, 2, 2 * p.n_cchunks) <= 160 * 1024) nw = 2 * p.n_cchunks;
+  if (allow_resident && p.n_cchunks <= 2 && conv_stream_lds(p, (int)buf, 2, 2 * p.n_cchunks) <= 160 * 1024)
+    nw = 2 * p.n_cchunks;
   if (conv_stream_lds(p, (int)buf, nb, nw) > 160 * 1024) nb = 2;
   if (conv_stream_lds(p, (int)buf, nb, nw) > 160 * 1024) return false;
   const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
@@ -602,6 +604,10 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     {
       ConvTile st;
       if (stream_tile(p, c, N, H_pos, W_pos, &st)) out->push_back(st);   // streaming, LDS-DMA operands
+      // two-chunk layers: resident weights leave room for 2 halo buffers, the weight ring for 3
+      if (p.n_cchunks == 2 && st.nt && st.n_wslots != 3 && stream_tile(p, c, N, H_pos, W_pos, &st, false) &&
+          st.n_bufs == 3)
+        out->push_back(st);
     }
   }
 }

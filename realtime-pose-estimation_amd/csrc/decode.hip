@@ -440,6 +440,68 @@ __global__ void __launch_bounds__(64) adjust_prepare_kernel(Map m, int J, int h,
   }
 }
 
+// (1b) shortcut for the arg-max of refine (group.py:229-233).  The score of person p at pixel x is
+//      det(x) - round(|tag(x) - mean_p|) <= det(x).  Let q* be the FIRST pixel attaining max det of the
+//      plane: if the penalty of p at q* is 0, then q* is exactly np.argmax of p's score map (no pixel
+//      can score higher than max det, and one that ties it is a later det maximum).  Only the
+//      (person, joint) pairs whose penalty at q* is not 0 need the full scan below.
+template <class Map>
+__global__ void __launch_bounds__(256) plane_argmax_kernel(Map m, int h, int w, u64* plane_key) {
+  __shared__ u64 red[4];
+  const int plane = blockIdx.y;
+  const int rows = (h + gridDim.x - 1) / gridDim.x;
+  const int y_begin = blockIdx.x * rows, y_end = min(h, y_begin + rows);
+  if (y_begin >= y_end) return;
+  const int npix = (y_end - y_begin) * w;
+  float bv = -INFINITY;
+  unsigned bi = 0xffffffffu;
+  int y = y_begin + (int)(threadIdx.x / (unsigned)w), x = (int)(threadIdx.x % (unsigned)w);
+  const int dy = 256 / w, dx = 256 - dy * w;
+  for (int i = threadIdx.x; i < npix; i += 256) {
+    const float dv = m.at(plane, y, x);
+    const bool up = dv > bv || bi == 0xffffffffu;          // increasing index order: '>' keeps the first maximum
+    bv = up ? dv : bv;
+    bi = up ? (unsigned)(y * w + x) : bi;
+    x += dx; y += dy;
+    if (x >= w) { x -= w; y += 1; }
+  }
+  const u64 k = block_max(bi == 0xffffffffu ? 0 : make_key(bv, bi), red);
+  if (threadIdx.x == 0 && k != 0) atomicMax(&plane_key[plane], k);
+}
+
+template <class TagMap>
+__global__ void __launch_bounds__(256) refine_shortcut_kernel(TagMap tm, int J, int w, int D, const float* ans_in,
+                                                              const int* person_img, int P, const float* mean_tag,
+                                                              const u64* plane_key, u64* best_key,
+                                                              unsigned char* need_scan) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P * J) return;
+  const int p = i / J, j = i - p * J;
+  const int row_len = 3 + D;
+  need_scan[i] = 0;
+  if (ans_in[(size_t)i * row_len + 2] != 0.f) return;       // only missing joints are refined
+  const int plane = (person_img ? person_img[p] : 0) * J + j;
+  const u64 key = plane_key[plane];
+  if (key == 0) { need_scan[i] = 1; return; }
+  const int idx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+  const int y = idx / w, x = idx - y * w;
+  float ss;                                                  // the exact expressions of refine_scan_kernel
+  if (D == 1) {
+    const float d0 = tm.at(plane, y, x, 0) - mean_tag[p];
+    ss = d0 * d0;
+  } else if (D < 8) {
+    const float d0 = tm.at(plane, y, x, 0) - mean_tag[(size_t)p * D];
+    ss = d0 * d0;
+    for (int d = 1; d < D; ++d) { const float dd = tm.at(plane, y, x, d) - mean_tag[(size_t)p * D + d]; ss = ss + dd * dd; }
+  } else {
+    float sq[kMaxD];
+    for (int d = 0; d < D; ++d) { const float dd = tm.at(plane, y, x, d) - mean_tag[(size_t)p * D + d]; sq[d] = dd * dd; }
+    ss = pairwise8_sum(sq, D);
+  }
+  if (rintf(sqrtf(ss)) == 0.f) best_key[i] = key;            // score = det - 0: the key of the plane maximum
+  else need_scan[i] = 1;
+}
+
 // (2) one block per (image, joint, row stripe): every person of the image that
 //     misses this joint is scored against every pixel of the stripe; the map is
 //     sampled once per pixel for all of them.  arg-max keys are merged with
@@ -447,7 +509,8 @@ __global__ void __launch_bounds__(64) adjust_prepare_kernel(Map m, int J, int h,
 template <class Map, class TagMap, bool kD1>
 __global__ void __launch_bounds__(256) refine_scan_kernel(Map m, TagMap tm, int J, int h, int w, int D,
                                                           const float* ans_in, const int* person_img, int P,
-                                                          const float* mean_tag, u64* best_key) {
+                                                          const float* mean_tag, u64* best_key,
+                                                          const unsigned char* need_scan) {
   __shared__ int lo_hi[2];
   __shared__ int n_need;
   __shared__ int need[512];
@@ -480,7 +543,8 @@ __global__ void __launch_bounds__(256) refine_scan_kernel(Map m, TagMap tm, int 
     if (threadIdx.x == 0) n_need = 0;
     __syncthreads();
     for (int p = base + threadIdx.x; p < min(hi, base + 512); p += 256)
-      if (ans_in[((size_t)p * J + j) * row_len + 2] == 0.f) need[atomicAdd(&n_need, 1)] = p;
+      if (ans_in[((size_t)p * J + j) * row_len + 2] == 0.f && (need_scan == nullptr || need_scan[(size_t)p * J + j]))
+        need[atomicAdd(&n_need, 1)] = p;
     __syncthreads();
     const int nn = n_need;
     for (int g0 = 0; g0 < nn; g0 += kRefineGroup) {
@@ -601,8 +665,10 @@ __global__ void __launch_bounds__(256) refine_finalize_kernel(Map m, int J, int 
   }
 }
 
+constexpr int kShortcutPlanes = 1 << 16;   // plane maxima kept for the arg-max shortcut (more planes: full scans only)
 static size_t refine_scratch(int P, int J, int D) {
-  return (size_t)P * J * sizeof(u64) + (size_t)P * D * sizeof(float) + 256;
+  return (size_t)P * J * sizeof(u64) + (size_t)P * D * sizeof(float) + 256 + (size_t)kShortcutPlanes * sizeof(u64) +
+         (size_t)P * J;
 }
 
 template <class Map, class TagMap>
@@ -617,12 +683,24 @@ static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, i
   RTPE_HIP_CHECK(hipGetLastError());
   if (!do_refine) return RTPE_OK;
   RTPE_HIP_CHECK(hipMemsetAsync(best_key, 0, (size_t)P * J * sizeof(u64), s));
+  unsigned char* need_scan = nullptr;
+  if (n_img * J <= kShortcutPlanes) {
+    char* tail = reinterpret_cast<char*>(mean_tag + (size_t)P * D);
+    u64* plane_key = reinterpret_cast<u64*>(tail + ((256 - ((uintptr_t)tail & 255)) & 255));
+    need_scan = reinterpret_cast<unsigned char*>(plane_key + kShortcutPlanes);
+    RTPE_HIP_CHECK(hipMemsetAsync(plane_key, 0, (size_t)n_img * J * sizeof(u64), s));
+    hipLaunchKernelGGL((plane_argmax_kernel<Map>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s, m, h, w, plane_key);
+    RTPE_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((refine_shortcut_kernel<TagMap>), dim3((P * J + 255) / 256), dim3(256), 0, s, tm, J, w, D, ans_in,
+                       person_img, P, mean_tag, plane_key, best_key, need_scan);
+    RTPE_HIP_CHECK(hipGetLastError());
+  }
   if (D == 1)
     hipLaunchKernelGGL((refine_scan_kernel<Map, TagMap, true>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s,
-                       m, tm, J, h, w, D, ans_in, person_img, P, mean_tag, best_key);
+                       m, tm, J, h, w, D, ans_in, person_img, P, mean_tag, best_key, need_scan);
   else
     hipLaunchKernelGGL((refine_scan_kernel<Map, TagMap, false>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s,
-                       m, tm, J, h, w, D, ans_in, person_img, P, mean_tag, best_key);
+                       m, tm, J, h, w, D, ans_in, person_img, P, mean_tag, best_key, need_scan);
   RTPE_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL((refine_finalize_kernel<Map>), dim3((P * J + 255) / 256), dim3(256), 0, s, m, J, h, w, D,
                      ans_in, ans_out, person_img, P, best_key);
