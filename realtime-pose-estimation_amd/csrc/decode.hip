@@ -136,7 +136,7 @@ struct AxisTab {
 
 template <class Map>
 __device__ __forceinline__ void fill_raw(const Map& m, int plane, int h, int w, int y0, int x0, int pad, float* raw,
-                                         AxisTab*, AxisTab*) {
+                                         AxisTab*, AxisTab*, float*, int) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH * PW; i += 256) {
     const int py = i / PW, px = i - py * PW;
@@ -147,7 +147,8 @@ __device__ __forceinline__ void fill_raw(const Map& m, int plane, int h, int w, 
 
 template <>
 __device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int plane, int h, int w, int y0, int x0,
-                                                      int pad, float* raw, AxisTab* ty, AxisTab* tx) {
+                                                      int pad, float* raw, AxisTab* ty, AxisTab* tx, float* stage,
+                                                      int stage_floats) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH + PW; i += 256) {
     const bool isy = i < PH;
@@ -163,6 +164,21 @@ __device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int 
   __syncthreads();
   const int n = plane / m.J, j = plane - n * m.J;
   const float* b = m.p + (size_t)n * m.img_stride + (size_t)j * m.sh * m.sw;
+  // The source pixels a tile needs form a small rectangle (about half the tile per axis when the map
+  // is upsampled 2x): stage it in LDS once (in `stage`, the row-max buffer, free at this point) and take
+  // the four taps of every sample from there instead of from L1; same arithmetic, same result.
+  const int ky0 = max(0, pad - y0), ky1 = min(PH - 1, h - 1 - (y0 - pad));
+  const int kx0 = max(0, pad - x0), kx1 = min(PW - 1, w - 1 - (x0 - pad));
+  const int sr0 = ty->i0[ky0], sr1 = ty->i1[ky1], sc0 = tx->i0[kx0], sc1 = tx->i1[kx1];
+  const int er = sr1 - sr0 + 1, ec = sc1 - sc0 + 1;
+  const bool staged = stage != nullptr && ky0 <= ky1 && kx0 <= kx1 && er > 0 && ec > 0 && er * ec <= stage_floats;
+  if (staged) {
+    for (int i = threadIdx.x; i < er * ec; i += 256) {
+      const int r = i / ec, c = i - r * ec;
+      stage[i] = b[(sr0 + r) * m.sw + sc0 + c];
+    }
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < PH * PW; i += 256) {
     const int py = i / PW, px = i - py * PW;
     const int r0 = ty->i0[py], c0 = tx->i0[px];
@@ -170,14 +186,22 @@ __device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int 
     if (r0 >= 0 && c0 >= 0) {
       const int r1 = ty->i1[py], c1 = tx->i1[px];
       const float ly0 = ty->l0[py], ly1 = ty->l1[py], lx0 = tx->l0[px], lx1 = tx->l1[px];
-      const float v00 = b[r0 * m.sw + c0], v01 = b[r0 * m.sw + c1];
-      const float v10 = b[r1 * m.sw + c0], v11 = b[r1 * m.sw + c1];
+      float v00, v01, v10, v11;
+      if (staged) {
+        const float* s0 = stage + (r0 - sr0) * ec - sc0;
+        const float* s1 = stage + (r1 - sr0) * ec - sc0;
+        v00 = s0[c0]; v01 = s0[c1]; v10 = s1[c0]; v11 = s1[c1];
+      } else {
+        v00 = b[r0 * m.sw + c0]; v01 = b[r0 * m.sw + c1];
+        v10 = b[r1 * m.sw + c0]; v11 = b[r1 * m.sw + c1];
+      }
       const float t0 = __builtin_fmaf(v00, lx0, v01 * lx1);
       const float t1 = __builtin_fmaf(v10, lx0, v11 * lx1);
       v = __builtin_fmaf(t0, ly0, t1 * ly1);
     }
     raw[i] = v;
   }
+  if (staged) __syncthreads();                          // `stage` becomes the row-max buffer again
 }
 
 template <class Map>
@@ -185,7 +209,7 @@ __device__ __forceinline__ void nms_tile(const Map& m, int plane, int h, int w, 
                                          float* raw, float* rowmax, AxisTab* ty, AxisTab* tx) {
   // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
-  fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx);
+  fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, (kTH + 2 * kMaxPad) * kTW);
   __syncthreads();
   for (int i = threadIdx.x; i < PH * kTW; i += 256) {
     const int py = i / kTW, px = i - py * kTW;
