@@ -244,8 +244,9 @@ __global__ void __launch_bounds__(256) nms_kernel(Map m, int h, int w, int pad, 
 // ---------------------------------------------------------------------------
 // top-K, phase 1: per tile, the K best positive local maxima as sorted keys
 // ---------------------------------------------------------------------------
-template <class Map>
-__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad, int K, u64* cand) {
+template <class Map, int PAD>     // PAD >= 0: the NMS padding as a compile-time constant (divisions by PW become shifts/muls)
+__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad_rt, int K, u64* cand) {
+  const int pad = PAD >= 0 ? PAD : pad_rt;
   __shared__ float raw[(kTH + 2 * kMaxPad) * (kTW + 2 * kMaxPad)];
   __shared__ float rowmax[(kTH + 2 * kMaxPad) * kTW];
   __shared__ u64 red[4];
@@ -470,25 +471,102 @@ __global__ void __launch_bounds__(64) adjust_prepare_kernel(Map m, int J, int h,
 //      can score higher than max det, and one that ties it is a later det maximum).  Only the
 //      (person, joint) pairs whose penalty at q* is not 0 need the full scan below.
 template <class Map>
-__global__ void __launch_bounds__(256) plane_argmax_kernel(Map m, int h, int w, u64* plane_key) {
+__device__ __forceinline__ void argmax_rows(const Map& m, int plane, int w, int y_begin, int y_end, float* bv,
+                                            unsigned* bi, float*, int) {
+  const int npix = (y_end - y_begin) * w;
+  int y = y_begin + (int)(threadIdx.x / (unsigned)w), x = (int)(threadIdx.x % (unsigned)w);
+  const int dy = 256 / w, dx = 256 - dy * w;
+  for (int i = threadIdx.x; i < npix; i += 256) {
+    const float dv = m.at(plane, y, x);
+    const bool up = dv > *bv || *bi == 0xffffffffu;          // increasing index order: '>' keeps the first maximum
+    *bv = up ? dv : *bv;
+    *bi = up ? (unsigned)(y * w + x) : *bi;
+    x += dx; y += dy;
+    if (x >= w) { x -= w; y += 1; }
+  }
+}
+
+// bilinear maps: a thread owns up to 8 fixed columns (their x-axis taps and weights stay in registers),
+// the y-axis taps of a row are the same for the whole block; per pixel 4 loads + 5 flops remain
+template <>
+__device__ __forceinline__ void argmax_rows<BilinearMap>(const BilinearMap& m, int plane, int w, int y_begin,
+                                                         int y_end, float* bv, unsigned* bi, float* lds,
+                                                         int lds_floats) {
+  constexpr int kCols = 8;
+  if (w > 256 * kCols) {                                      // very wide maps: the generic walk
+    const int npix = (y_end - y_begin) * w;
+    int y = y_begin + (int)(threadIdx.x / (unsigned)w), x = (int)(threadIdx.x % (unsigned)w);
+    const int dy = 256 / w, dx = 256 - dy * w;
+    for (int i = threadIdx.x; i < npix; i += 256) {
+      const float dv = m.at(plane, y, x);
+      const bool up = dv > *bv || *bi == 0xffffffffu;
+      *bv = up ? dv : *bv;
+      *bi = up ? (unsigned)(y * w + x) : *bi;
+      x += dx; y += dy;
+      if (x >= w) { x -= w; y += 1; }
+    }
+    return;
+  }
+  const int n = plane / m.J, j = plane - n * m.J;
+  const float* b = m.p + (size_t)n * m.img_stride + (size_t)j * m.sh * m.sw;
+  // the source rows of the stripe are contiguous in memory: one coalesced copy into LDS, then the four
+  // taps of every pixel come from there (the gather of 4-byte taps through L1 was the whole cost)
+  int sr0, sr1, t0i, t1i;
+  float tf0, tf1;
+  m.ay.at(y_begin, &sr0, &t0i, &tf0, &tf1);
+  m.ay.at(y_end - 1, &t1i, &sr1, &tf0, &tf1);
+  const int nsrc = (sr1 - sr0 + 1) * m.sw;
+  const bool staged = lds != nullptr && nsrc > 0 && nsrc <= lds_floats;
+  if (staged) {
+    const float* g = b + sr0 * m.sw;
+    for (int i = threadIdx.x; i < nsrc; i += 256) lds[i] = g[i];
+    __syncthreads();
+  }
+  int c0[kCols], c1[kCols];
+  float lx0[kCols], lx1[kCols];
+#pragma unroll
+  for (int k = 0; k < kCols; ++k) {
+    const int x = threadIdx.x + k * 256;
+    c0[k] = c1[k] = 0; lx0[k] = lx1[k] = 0.f;
+    if (x < w) m.ax.at(x, &c0[k], &c1[k], &lx0[k], &lx1[k]);
+  }
+  for (int y = y_begin; y < y_end; ++y) {
+    int r0, r1;
+    float ly0, ly1;
+    m.ay.at(y, &r0, &r1, &ly0, &ly1);
+    const int o0 = (staged ? r0 - sr0 : r0) * m.sw, o1 = (staged ? r1 - sr0 : r1) * m.sw;
+#pragma unroll
+    for (int k = 0; k < kCols; ++k) {
+      const int x = threadIdx.x + k * 256;
+      if (x < w) {
+        float v00, v01, v10, v11;
+        if (staged) {                                         // uniform branch: LDS taps
+          v00 = lds[o0 + c0[k]]; v01 = lds[o0 + c1[k]]; v10 = lds[o1 + c0[k]]; v11 = lds[o1 + c1[k]];
+        } else {
+          v00 = b[o0 + c0[k]]; v01 = b[o0 + c1[k]]; v10 = b[o1 + c0[k]]; v11 = b[o1 + c1[k]];
+        }
+        const float t0 = __builtin_fmaf(v00, lx0[k], v01 * lx1[k]);
+        const float t1 = __builtin_fmaf(v10, lx0[k], v11 * lx1[k]);
+        const float dv = __builtin_fmaf(t0, ly0, t1 * ly1);
+        const bool up = dv > *bv || *bi == 0xffffffffu;      // a thread's pixels come in increasing index order
+        *bv = up ? dv : *bv;
+        *bi = up ? (unsigned)(y * w + x) : *bi;
+      }
+    }
+  }
+}
+
+template <class Map>
+__global__ void __launch_bounds__(256) plane_argmax_kernel(Map m, int h, int w, u64* plane_key, int lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float argmax_src[];
   __shared__ u64 red[4];
   const int plane = blockIdx.y;
   const int rows = (h + gridDim.x - 1) / gridDim.x;
   const int y_begin = blockIdx.x * rows, y_end = min(h, y_begin + rows);
   if (y_begin >= y_end) return;
-  const int npix = (y_end - y_begin) * w;
   float bv = -INFINITY;
   unsigned bi = 0xffffffffu;
-  int y = y_begin + (int)(threadIdx.x / (unsigned)w), x = (int)(threadIdx.x % (unsigned)w);
-  const int dy = 256 / w, dx = 256 - dy * w;
-  for (int i = threadIdx.x; i < npix; i += 256) {
-    const float dv = m.at(plane, y, x);
-    const bool up = dv > bv || bi == 0xffffffffu;          // increasing index order: '>' keeps the first maximum
-    bv = up ? dv : bv;
-    bi = up ? (unsigned)(y * w + x) : bi;
-    x += dx; y += dy;
-    if (x >= w) { x -= w; y += 1; }
-  }
+  argmax_rows(m, plane, w, y_begin, y_end, &bv, &bi, lds_floats > 0 ? argmax_src : nullptr, lds_floats);
   const u64 k = block_max(bi == 0xffffffffu ? 0 : make_key(bv, bi), red);
   if (threadIdx.x == 0 && k != 0) atomicMax(&plane_key[plane], k);
 }
@@ -713,7 +791,8 @@ static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, i
     u64* plane_key = reinterpret_cast<u64*>(tail + ((256 - ((uintptr_t)tail & 255)) & 255));
     need_scan = reinterpret_cast<unsigned char*>(plane_key + kShortcutPlanes);
     RTPE_HIP_CHECK(hipMemsetAsync(plane_key, 0, (size_t)n_img * J * sizeof(u64), s));
-    hipLaunchKernelGGL((plane_argmax_kernel<Map>), dim3(kRefineStripes, n_img * J), dim3(256), 0, s, m, h, w, plane_key);
+    hipLaunchKernelGGL((plane_argmax_kernel<Map>), dim3(kRefineStripes, n_img * J), dim3(256), 48 * 1024, s, m, h, w,
+                       plane_key, 48 * 1024 / 4);
     RTPE_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((refine_shortcut_kernel<TagMap>), dim3((P * J + 255) / 256), dim3(256), 0, s, tm, J, w, D, ans_in,
                        person_img, P, mean_tag, plane_key, best_key, need_scan);
@@ -757,7 +836,10 @@ static int topk_run(const Map& m, const TagMap& tm, int planes, int tag_shared_j
   RTPE_REQUIRE(scratch_bytes >= topk_scratch(planes, h, w, K), "topk: scratch too small");
   const int tiles = ((h + kTH - 1) / kTH) * ((w + kTW - 1) / kTW);
   u64* cand = reinterpret_cast<u64*>(scratch);
-  hipLaunchKernelGGL((topk_tile_kernel<Map>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
+  if (pad == 2)
+    hipLaunchKernelGGL((topk_tile_kernel<Map, 2>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
+  else
+    hipLaunchKernelGGL((topk_tile_kernel<Map, -1>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
   RTPE_HIP_CHECK(hipGetLastError());
   size_t lds = 32 + (size_t)tiles * K * 8;
   if (lds > 150 * 1024) lds = 32;
