@@ -155,7 +155,7 @@ def main():
         t = eng.op_tile(i, B, S, S)
         ds = eng.program.tensors[eng.program.ops[i].out_t].ds_log2 if eng.program.ops[i].out_t >= 0 else 1
         names[i] = "%s @/%d" % (names[i], 1 << ds) + (
-            " [m%d n%d w%d %dx%d cc%d cb%d%s]" % (tuple(t[:7]) + ((" S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else "",)) if t[0] else "")
+            " [m%d n%d w%d %dx%d cc%d cb%d%s]" % (tuple(t[:7]) + ((" FUSED-BLOCK" if t[7] == -900001 else " (in fused block)" if t[7] == -900002 else " S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else "",)) if t[0] else "")
     for i, nm in enumerate(names):
         d = by_name.setdefault(nm, dict(n=0, ms=0.0, flops=0.0, bytes=0.0, res={}))
         d["n"] += 1
@@ -165,15 +165,26 @@ def main():
     # dominant = the fused 3x3 C=48 BasicBlock conv at 160x160 (64 launches / forward)
     dom_idx = [i for i, nm in enumerate(names) if nm.startswith("conv 48->48 k3s1")
                and eng.program.tensors[eng.program.ops[i].out_t].ds_log2 == 2]
-    dom_ms = float(np.mean([op_ms[i] for i in dom_idx]))
-    dom_bytes = float(np.mean([costs[i][1] for i in dom_idx]))
-    dom_flops = float(np.mean([costs[i][0] for i in dom_idx]))
+    dom_tiles = [eng.op_tile(i, B, S, S) for i in dom_idx]
+    heads = [i for i, t in zip(dom_idx, dom_tiles) if t[7] == -900001]
+    if heads and len(heads) * 2 == len(dom_idx):
+        # the two convs of a BasicBlock run as ONE kernel: a launch = the block, its algorithmic bytes =
+        # the layer-fused traffic of both convs (conv in + out, + residual), its time = the pair's
+        dom_launches = len(heads)
+        dom_ms = float(np.mean([op_ms[i] + op_ms[i + 1] for i in heads]))
+        dom_bytes = float(np.mean([costs[i][1] + costs[i + 1][1] for i in heads]))
+        dom_flops = float(np.mean([costs[i][0] + costs[i + 1][0] for i in heads]))
+        dom_kernel = "conv_block_kernel (fused BasicBlock: conv+BN+ReLU+conv+BN+add+ReLU)"
+    else:
+        dom_launches = len(dom_idx)
+        dom_ms = float(np.mean([op_ms[i] for i in dom_idx]))
+        dom_bytes = float(np.mean([costs[i][1] for i in dom_idx]))
+        dom_flops = float(np.mean([costs[i][0] for i in dom_idx]))
+        dom_kernel = "conv_stream_kernel<3,*,4>" if all(t[7] <= -100000 for t in dom_tiles) else \
+            "conv_mfma_kernel<3,*,4>" if all(t[7] > 0 for t in dom_tiles) else "conv_stream_kernel / conv_mfma_kernel"
     total_flops = sum(c[0] for c in costs)
     total_bytes = sum(c[1] for c in costs)
     fwd_ms_events = float(op_ms.sum())
-    dom_tiles = [eng.op_tile(i, B, S, S) for i in dom_idx]
-    dom_kernel = "conv_stream_kernel" if all(t[7] <= -100000 for t in dom_tiles) else \
-        "conv_mfma_kernel" if all(t[7] > 0 for t in dom_tiles) else "conv_stream_kernel / conv_mfma_kernel"
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured with
     # rocprofv3 on this kernel and committed under profiles/ (bench.py cannot run the profiler on itself)
     traffic = traffic_src = None
@@ -182,12 +193,12 @@ def main():
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("kernel", "").startswith(dom_kernel) and tj.get("batch") == B:
+            if tj.get("kernel", "").split("<")[0].split(" ")[0] == dom_kernel.split("<")[0].split(" ")[0] and tj.get("batch") == B:
                 traffic, traffic_src = float(tj["hbm_bytes_per_launch"]["mean"]), "profiles/r01_hbm_traffic.json"
         except (ValueError, KeyError):
             pass
     roofline = {
-        "kernel": "%s<3,*,4> 3x3 s1 48->48 @160x160 (BasicBlock conv, %d launches/forward)" % (dom_kernel, len(dom_idx)),
+        "kernel": "%s, 3x3 s1 48->48 @160x160, %d launches/forward" % (dom_kernel, dom_launches),
         "bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
         "traffic_source": traffic_src,

@@ -183,12 +183,22 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
 /* kernel variant of conv op i for (N,H,W): out8 = {cout tiles/wave, pixel
  * tiles/wave, waves, tile_h, tile_w, channel chunk, cout blocks, v} with
  * v > 0: LDS bytes of the one-workgroup-per-tile kernel; v <= -100000:
- * -(workgroups + 100000 * halo buffers) of the streaming kernel */
+ * -(workgroups + 100000 * halo buffers) of the streaming kernel; -900001 / -900002: first /
+ * second conv of a BasicBlock that runs as ONE fused kernel (conv_block.hip), launched by the
+ * first */
 int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8);
 
 /* ------------------------------------------------------------------------ *
  * Single layers (layer-level parity tests; same kernels the executor runs).
  * ------------------------------------------------------------------------ */
+
+/* One BasicBlock of a 48-channel branch (pose_higher_hrnet.py:46-75) as a single fused kernel:
+ * y = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x), NHWC fp16 (N,H,W,48) in and out, weights
+ * (48,48,3,3) fp16 on the host, BatchNorm as fp32 alpha/beta[48].  Bit-identical to two
+ * rtpe_conv2d_nhwc calls (layer-level parity tests).  Host-returning. */
+int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t W, const void* w1_host,
+                         const float* alpha1, const float* beta1, const void* w2_host,
+                         const float* alpha2, const float* beta2, void* y, void* stream);
 
 /* NHWC fp16 conv: y = act( round16( round16?(conv(x,w)) * alpha + beta ) [+ res] ).
  * w: HOST pointer, fp16 OIHW (cout,cin,k,k); alpha/beta: HOST fp32[cout].

@@ -1,0 +1,428 @@
+// Fused BasicBlock for the 48-channel branches of the w48 network (pose_higher_hrnet.py:46-75):
+//     y = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )
+// in ONE kernel.  The two convolutions of a 48-channel block at 160x160 / 320x320 are the layers
+// that sit at the chip's mixed read/write bandwidth ceiling when run one after the other (conv1:
+// read x, write mid; conv2: read mid, read x as the residual, write y = 5 tensor passes).  Here
+// the intermediate tile never leaves LDS and the residual is the input tile that is already
+// there: read x once (+ halo), write y once.
+//
+// Same math as conv_stream.hip / conv_mfma.hip (same k order, same packed weights, same rounding
+// points: conv -> fp16, BN -> fp16, ReLU, (add -> fp16)), so the result is bit-identical to the
+// two separate launches.  Per unit = 6x32 output pixels of one image:
+//   * x halo tile 10x36 pixels, LDS-DMA'd by two loader waves one unit ahead (2 buffers);
+//   * conv1 on the 8x34 region the second conv needs (272 pixels in 5 x 16-pixel tiles per wave;
+//     48 slots idle), BN1 + ReLU in registers, written as fp16 rows into the mid tile in LDS
+//     (zeros outside the image = conv2's padding);
+//   * conv2 on the 6x32 outputs (3 tiles per wave) straight from the mid tile;
+//   * BN2, transposition through LDS, + x (16-byte row pieces of the halo tile), ReLU, store;
+//   * the weights of both convs (4 half-stage sets of 21 KiB) stream through the 3-slot LDS ring
+//     of conv_stream.hip, two half stages ahead, from L2.
+// LDS: 63 KiB ring + 2 x 33.75 KiB x tiles + 25.5 KiB mid tile = 156 KiB, one workgroup per CU.
+#include <type_traits>
+
+#include "rtpe_common.h"
+
+namespace rtpe {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef short short8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kTH = 6, kTW = 32;                 // output tile
+constexpr int kMH = kTH + 2, kMW = kTW + 2;      // conv1 region = mid tile (8 x 34)
+constexpr int kXH = kTH + 4, kXW = kTW + 4;      // x halo tile (10 x 36)
+constexpr int kPS = 96;                          // LDS bytes per pixel (48 fp16 channels)
+constexpr int kMT = 3;                           // 48 output channels = 3 MFMA row tiles
+constexpr int kNT1 = 5, kNT2 = 3;                // 16-pixel tiles per wave: conv1 (320 slots for 272), conv2 (192)
+constexpr int kWaves = 4, kLoad = 3;
+constexpr int kKH = 7;                           // k-steps per half stage
+constexpr int kWSlot = kMT * kKH * 1024;         // 21,504 B
+constexpr int kXBytes = kXH * kXW * kPS;         // 34,560 B
+constexpr int kMidBytes = kMH * kMW * kPS;       // 26,112 B
+constexpr int kRowB = kMT * 32 + 16;             // transposed output row in LDS
+constexpr int kLds = 3 * kWSlot + 2 * kXBytes + kMidBytes;
+
+#define RTPE_BBARRIER()                         \
+  do {                                          \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+  } while (0)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+}  // namespace
+
+struct BlockArgs {
+  const _Float16* x;
+  _Float16* y;
+  const _Float16* w1;       // packed fragments [14 k-steps][3][64 lanes][16 B]
+  const _Float16* w2;
+  const float* ab1;         // alpha[48], beta[48]
+  const float* ab2;
+  int N, H, W, in_ld, out_ld;
+  int tiles_x, tiles_y;
+  FastDiv div_tiles_x, div_tiles_xy;
+  int x_bytes;
+};
+
+__global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wring = smem;
+  char* const xt = smem + 3 * kWSlot;
+  char* const mid = xt + 2 * kXBytes;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD x (= blockIdx % 8) owns a CONTIGUOUS eighth of the tile list (row-major tiles of consecutive
+  // images) and its G workgroups walk it with stride G: tiles that share halo rows (t and t +- tiles_x)
+  // are multiplied on the same XCD at about the same time, so the overlap comes from that XCD's L2
+  const int n_tiles = a.N * a.tiles_x * a.tiles_y;
+  const int G = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd;
+  const int tiles_xcd = min(per_xcd, n_tiles - t_begin);               // may be <= 0 for the last XCDs
+  const int U = jw < tiles_xcd ? (tiles_xcd - jw + G - 1) / G : 0;      // units of this workgroup
+  if (U == 0) return;
+  const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
+  auto unit_origin = [&](int u, uint32_t* n, int* py0, int* px0) __attribute__((always_inline)) {
+    uint32_t t = (uint32_t)(t_begin + jw + u * G);
+    *n = fdiv(t, a.div_tiles_xy);
+    t -= *n * tiles_xy;
+    const uint32_t tyi = fdiv(t, a.div_tiles_x);
+    *py0 = (int)tyi * kTH;
+    *px0 = (int)(t - tyi * a.tiles_x) * kTW;
+  };
+
+  if (wv == kWaves) {
+    // ----------------------------- weight loader -----------------------------
+    // half stage q = 4 u + i : i = 0,1 -> conv1 halves, i = 2,3 -> conv2 halves; ring slot q % 3
+    __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w1), 0, 2 * kWSlot, 0x00020000);
+    __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w2), 0, 2 * kWSlot, 0x00020000);
+    const int voff = lane * 16;
+    auto issue = [&](int q) __attribute__((always_inline)) {
+      const int i = q & 3;
+      char* dst = wring + (q % 3) * kWSlot;
+      const int src = (i & 1) * kWSlot;
+      if (i < 2) {
+#pragma unroll
+        for (int p = 0; p < kMT * kKH; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(dst + p * 1024), 16, voff, src + p * 1024, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < kMT * kKH; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(dst + p * 1024), 16, voff, src + p * 1024, 0, 0);
+      }
+    };
+    const int Q = 4 * U;
+    issue(0);
+    issue(1);
+    for (int q = 0; q < Q; ++q) {
+      // half q has landed (only the most recent half may still be in flight), hand it over at the
+      // barrier that starts it (M, H1, A2, H2 of the unit), then request half q + 2
+      if (q + 1 < Q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMT * kKH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RTPE_BBARRIER();
+      if (q + 2 < Q) issue(q + 2);
+      if ((q & 3) == 3) RTPE_BBARRIER();                 // E2 of the unit
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  if (wv > kWaves) {
+    // ------------------------------ tile loaders ------------------------------
+    const int jl = wv - kWaves - 1;                      // rows [0,5) or [5,10) of every x tile
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, a.x_bytes, 0x00020000);
+    constexpr int rowslots = kXW * 6;                    // 216 16-byte slots per halo row
+    auto issue = [&](int u) __attribute__((always_inline)) {
+      uint32_t n;
+      int py0, px0;
+      unit_origin(u, &n, &py0, &px0);
+      const int iy0 = py0 - 2, ix0 = px0 - 2;
+      uint32_t voff[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = k * 64 + lane;
+        const int hx = q / 6, sl = q - hx * 6;
+        const int ix = ix0 + hx;
+        voff[k] = (unsigned)ix < (unsigned)a.W ? (uint32_t)(ix * a.in_ld + sl * 8) * 2u : 0x80000000u;
+      }
+      char* buf = xt + (u & 1) * kXBytes;
+      const int img_row0 = (int)n * a.H;
+      for (int r = jl * (kXH / 2); r < (jl + 1) * (kXH / 2); ++r) {
+        const int iy = iy0 + r;
+        const bool row_ok = (unsigned)iy < (unsigned)a.H;
+        const int soff = row_ok ? (img_row0 + iy) * a.W * a.in_ld * 2 : 0;
+        char* dst = buf + r * (kXW * kPS);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k * 64 + lane < rowslots)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + k * 1024), 16,
+                                                     (int)(row_ok ? voff[k] : 0x80000000u), soff, 0, 0);
+      }
+    };
+    issue(0);
+    for (int u = 0; u < U; ++u) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this loader's rows of tile u have landed
+      RTPE_BBARRIER();                                   // M: x buffer (u+1)&1 is free (its last reader was epilogue B of u-1)
+      if (u + 1 < U) issue(u + 1);
+      RTPE_BBARRIER();                                   // H1
+      RTPE_BBARRIER();                                   // A2
+      RTPE_BBARRIER();                                   // H2
+      RTPE_BBARRIER();                                   // E2
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // -------------------------------- MFMA waves --------------------------------
+  const int r = lane & 15, g = lane >> 4;
+  // byte offset of this lane group's 8 channels in k-step k: conv1 walks the x tile (36 pixels
+  // per row), conv2 the mid tile (34 pixels per row)
+  int toff1[2 * kKH], toff2[2 * kKH];
+#pragma unroll
+  for (int k = 0; k < 2 * kKH; ++k) {
+    int kk = k * 32 + g * 8;
+    if (kk >= 9 * 48) kk -= 9 * 48;                      // zero-weight k padding: any finite in-tile data
+    const int tap = kk / 48, c = kk - tap * 48;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    toff1[k] = (ty * kXW + tx) * kPS + c * 2;
+    toff2[k] = (ty * kMW + tx) * kPS + c * 2;
+  }
+  int pix1[kNT1], pix2[kNT2];
+#pragma unroll
+  for (int nt = 0; nt < kNT1; ++nt) {
+    int p = (wv * kNT1 + nt) * 16 + r;
+    p = p < kMH * kMW ? p : kMH * kMW - 1;               // idle slots recompute the last pixel
+    const int my = p / kMW, mx = p - my * kMW;
+    pix1[nt] = (my * kXW + mx) * kPS;
+  }
+#pragma unroll
+  for (int nt = 0; nt < kNT2; ++nt) {
+    const int p = (wv * kNT2 + nt) * 16 + r;
+    pix2[nt] = ((p >> 5) * kMW + (p & 31)) * kPS;
+  }
+  float4v al1[kMT], be1[kMT], al2[kMT], be2[kMT];
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) {
+    const int c4 = m * 16 + g * 4;
+    al1[m] = *reinterpret_cast<const float4v*>(a.ab1 + c4);
+    be1[m] = *reinterpret_cast<const float4v*>(a.ab1 + 48 + c4);
+    al2[m] = *reinterpret_cast<const float4v*>(a.ab2 + c4);
+    be2[m] = *reinterpret_cast<const float4v*>(a.ab2 + 48 + c4);
+  }
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) asm volatile("" ::"v"(al1[m]), "v"(be1[m]), "v"(al2[m]), "v"(be2[m]));
+
+  int wsel = 0;                                          // ring slot of the next half stage (q % 3)
+  for (int u = 0; u < U; ++u) {
+    uint32_t n;
+    int py0, px0;
+    unit_origin(u, &n, &py0, &px0);
+    const char* xb = xt + (u & 1) * kXBytes;
+
+    // ------------------------------- conv1 -------------------------------
+    float4v acc1[kMT][kNT1];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kNT1; ++nt) acc1[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      RTPE_BBARRIER();                                   // M (x tile + half 0) / H1 (half 1)
+      const char* wl = wring + wsel * kWSlot + lane * 16;
+      wsel = wsel == 2 ? 0 : wsel + 1;
+      half8 af[2][kMT], bf[2][kNT1];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
+#pragma unroll
+      for (int nt = 0; nt < kNT1; ++nt) bf[0][nt] = *reinterpret_cast<const half8*>(xb + pix1[nt] + toff1[h * kKH]);
+#pragma unroll
+      for (int kk = 0; kk < kKH; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < kKH) {
+#pragma unroll
+          for (int m = 0; m < kMT; ++m) af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 1) * kMT + m) * 1024);
+#pragma unroll
+          for (int nt = 0; nt < kNT1; ++nt)
+            bf[nxt][nt] = *reinterpret_cast<const half8*>(xb + pix1[nt] + toff1[h * kKH + kk + 1]);
+        }
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+          for (int nt = 0; nt < kNT1; ++nt)
+            acc1[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc1[m][nt], 0, 0, 0);
+        if (kk + 1 < kKH) {
+#pragma unroll
+          for (int i = 0; i < kMT + kNT1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- epilogue A: BN1 + ReLU -> fp16 rows of the mid tile (the unfused path's HBM tensor) ----
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int re = lane_e & 15, ge = lane_e >> 4;
+#pragma unroll
+      for (int nt = 0; nt < kNT1; ++nt) {
+        const int p = (wv * kNT1 + nt) * 16 + re;
+        const int my = p / kMW, mx = p - my * kMW;
+        const int iy = py0 - 1 + my, ix = px0 - 1 + mx;
+        const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          const float4v v = acc1[m][nt];
+          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);      // conv output is fp16
+          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
+          lo = __builtin_elementwise_fma(lo, float2v{al1[m][0], al1[m][1]}, float2v{be1[m][0], be1[m][1]});
+          hi = __builtin_elementwise_fma(hi, float2v{al1[m][2], al1[m][3]}, float2v{be1[m][2], be1[m][3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+          half4 o{olo[0], olo[1], ohi[0], ohi[1]};
+          short4v b = __builtin_bit_cast(short4v, o);
+          b = b & ~(b >> 15);                                                                // ReLU on the sign bits
+          if (!inside) b = b ^ b;                                                            // conv2's zero padding
+          if (p < kMH * kMW)
+            *reinterpret_cast<short4v*>(mid + p * kPS + m * 32 + ge * 8) = b;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ------------------------------- conv2 -------------------------------
+    float4v acc2[kMT][kNT2];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kNT2; ++nt) acc2[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      RTPE_BBARRIER();                                   // A2 (mid tile complete + half 2) / H2 (half 3)
+      const char* wl = wring + wsel * kWSlot + lane * 16;
+      wsel = wsel == 2 ? 0 : wsel + 1;
+      half8 af[2][kMT], bf[2][kNT2];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
+#pragma unroll
+      for (int nt = 0; nt < kNT2; ++nt) bf[0][nt] = *reinterpret_cast<const half8*>(mid + pix2[nt] + toff2[h * kKH]);
+#pragma unroll
+      for (int kk = 0; kk < kKH; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < kKH) {
+#pragma unroll
+          for (int m = 0; m < kMT; ++m) af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 1) * kMT + m) * 1024);
+#pragma unroll
+          for (int nt = 0; nt < kNT2; ++nt)
+            bf[nxt][nt] = *reinterpret_cast<const half8*>(mid + pix2[nt] + toff2[h * kKH + kk + 1]);
+        }
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+          for (int nt = 0; nt < kNT2; ++nt)
+            acc2[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc2[m][nt], 0, 0, 0);
+        if (kk + 1 < kKH) {
+#pragma unroll
+          for (int i = 0; i < kMT + kNT2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- epilogue B: BN2, transposed through the (now free) mid tile, + x, ReLU, store ----
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int re = lane_e & 15, ge = lane_e >> 4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RTPE_BBARRIER();                                   // E2: every wave is done reading the mid tile
+      char* obuf = mid + wv * (kNT2 * 16 * kRowB);
+#pragma unroll
+      for (int nt = 0; nt < kNT2; ++nt)
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          const float4v v = acc2[m][nt];
+          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
+          lo = __builtin_elementwise_fma(lo, float2v{al2[m][0], al2[m][1]}, float2v{be2[m][0], be2[m][1]});
+          hi = __builtin_elementwise_fma(hi, float2v{al2[m][2], al2[m][3]}, float2v{be2[m][2], be2[m][3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
+        }
+      constexpr int NIT = (kNT2 * 16 * 6 + 63) / 64;     // 16-byte row pieces per lane
+      half8 ov[NIT], rv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int c = it * 64 + lane_e;
+        c = c < kNT2 * 16 * 6 ? c : 0;
+        const int pw = c / 6, slot = c - pw * 6;
+        const int p = wv * kNT2 * 16 + pw;
+        const int oy = p >> 5, ox = p & 31;
+        ov[it] = *reinterpret_cast<const half8*>(obuf + pw * kRowB + slot * 16);
+        rv[it] = *reinterpret_cast<const half8*>(xb + ((oy + 2) * kXW + ox + 2) * kPS + slot * 16);   // the block input
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 64 + lane_e;
+        const int pw = c / 6, slot = c - pw * 6;
+        const int p = wv * kNT2 * 16 + pw;
+        const int py = py0 + (p >> 5), px = px0 + (p & 31);
+        half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
+        short8 b = __builtin_bit_cast(short8, v);
+        b = b & ~(b >> 15);
+        if (c < kNT2 * 16 * 6 && py < a.H && px < a.W)
+          *reinterpret_cast<short8*>(a.y + (((size_t)n * a.H + py) * a.W + px) * a.out_ld + slot * 8) = b;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+bool conv_block_supports(int cin, int cout, int H, int W) { return cin == 48 && cout == 48 && H >= kTH && W >= 16; }
+
+int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,
+                      const float* ab1, const _Float16* w2, const float* ab2, int N, int H, int W, hipStream_t s) {
+  RTPE_REQUIRE(x && y && w1 && w2 && ab1 && ab2 && N > 0, "basic block: null argument");
+  RTPE_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= 48 && out_ld >= 48 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+               "basic block: NHWC views must be 16-byte aligned (in_ld=%d out_ld=%d)", in_ld, out_ld);
+  RTPE_REQUIRE(x_bytes > 0 && x_bytes < 0x80000000ull, "basic block: input view of %zu bytes", x_bytes);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  BlockArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.ab1 = ab1; a.ab2 = ab2;
+  a.N = N; a.H = H; a.W = W; a.in_ld = in_ld; a.out_ld = out_ld;
+  a.tiles_x = (W + kTW - 1) / kTW;
+  a.tiles_y = (H + kTH - 1) / kTH;
+  a.div_tiles_x = make_fastdiv(a.tiles_x);
+  a.div_tiles_xy = make_fastdiv(a.tiles_x * a.tiles_y);
+  a.x_bytes = (int)x_bytes;
+  const long tiles = (long)N * a.tiles_x * a.tiles_y;
+  long G = 32;                                            // one workgroup per CU
+  if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
+  hipLaunchKernelGGL(conv_block_kernel, dim3((unsigned)(8 * G)), dim3((kWaves + kLoad) * 64), kLds, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+}  // namespace rtpe

@@ -34,6 +34,7 @@ struct OpState {
   size_t w_dev_off[4];  // byte offsets in the device weight arena
   size_t ab_dev_off;    // alpha then beta, fp32[cout_pad]
   int n_geom;
+  int fuse;             // 1: head of a fused BasicBlock (this conv + the next run as one kernel), 2: its second conv
 };
 
 }  // namespace rtpe
@@ -135,6 +136,32 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     } else {
       set_error("op %d: unknown kind %d", i, d.kind); delete h; return RTPE_E_INVALID;
     }
+  }
+  // BasicBlock fusion (conv_block.hip): conv 48->48 k3 s1 +relu, then conv 48->48 k3 s1 +residual(+relu)
+  // whose residual is the first conv's input and whose input is read by nobody else
+  static const int fuse_blocks = getenv("RTPE_FUSE_BLOCKS") ? atoi(getenv("RTPE_FUSE_BLOCKS")) : 1;
+  for (size_t i = 0; fuse_blocks && i + 1 < h->ops.size(); ++i) {
+    OpState& a1 = h->ops[i];
+    OpState& a2 = h->ops[i + 1];
+    const rtpe_op_desc& d1 = a1.d;
+    const rtpe_op_desc& d2 = a2.d;
+    const int plain = RTPE_F_RELU | RTPE_F_ROUND_CONV;
+    if (a1.fuse || d1.kind != RTPE_OP_CONV || d2.kind != RTPE_OP_CONV) continue;
+    if (d1.cin != 48 || d1.cout != 48 || d2.cin != 48 || d2.cout != 48 || d1.ksize != 3 || d2.ksize != 3 ||
+        d1.stride != 1 || d2.stride != 1 || d1.flags != plain || d2.flags != plain || d1.res_t >= 0 ||
+        d2.res_t != d1.in_t || d2.res_coff != d1.in_coff || d2.in_t != d1.out_t || d2.in_coff != d1.out_coff ||
+        d1.reserved[1] > 1 || d2.reserved[1] > 1 || h->tensors[d1.in_t].reserved == 4 || d2.out_t == d1.in_t)
+      continue;
+    bool other_reader = false;                       // the intermediate tensor must die inside the block
+    for (size_t k = 0; k < h->ops.size() && !other_reader; ++k) {
+      if (k == i + 1) continue;
+      const rtpe_op_desc& dk = h->ops[k].d;
+      if (k > i && (dk.in_t == d1.out_t || dk.res_t == d1.out_t)) other_reader = true;
+      for (int t = 0; t < dk.n_terms && k > i; ++t) other_reader |= dk.term_t[t] == d1.out_t;
+    }
+    if (other_reader) continue;
+    a1.fuse = 1;
+    a2.fuse = 2;
   }
   h->arena_bytes = off;
 
@@ -258,6 +285,20 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.N = N; a.H = H; a.W = W; a.out_ld = to.channels;
       a.f32 = (d.flags & RTPE_F_F32) ? 1 : 0;
       rc = stem_launch(a, s);
+    } else if (d.kind == RTPE_OP_CONV && o.fuse == 2 && force == nullptr && only_op < 0) {
+      // second conv of a fused BasicBlock: done by the launch of its head
+    } else if (d.kind == RTPE_OP_CONV && o.fuse == 1 && force == nullptr && only_op < 0 &&
+               conv_block_supports(d.cin, d.cout, H >> h->tensors[d.in_t].ds_log2, W >> h->tensors[d.in_t].ds_log2)) {
+      const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+      const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
+      const OpState& o2 = h->ops[i + 1];
+      rc = conv_block_launch(tptr(d.in_t, d.in_coff), ti.channels,
+                             ((size_t)N * Hi * Wi * ti.channels - (size_t)d.in_coff) * 2,
+                             tptr(o2.d.out_t, o2.d.out_coff), h->tensors[o2.d.out_t].channels,
+                             reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[0]),
+                             reinterpret_cast<const float*>(h->arena + o.ab_dev_off),
+                             reinterpret_cast<const _Float16*>(h->arena + o2.w_dev_off[0]),
+                             reinterpret_cast<const float*>(h->arena + o2.ab_dev_off), N, Hi, Wi, s);
     } else if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
       const rtpe_tensor_desc& ti = h->tensors[d.in_t];
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
@@ -488,6 +529,39 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   return RTPE_OK;
 }
 
+extern "C" int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t W, const void* w1_host,
+                                    const float* alpha1, const float* beta1, const void* w2_host, const float* alpha2,
+                                    const float* beta2, void* y, void* stream) {
+  RTPE_REQUIRE(x && w1_host && w2_host && alpha1 && beta1 && alpha2 && beta2 && y, "basicblock_nhwc: null argument");
+  RTPE_REQUIRE(conv_block_supports(48, 48, H, W), "basicblock_nhwc: H=%d W=%d unsupported", H, W);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ConvGeom g{48, 48, 3, 1, -1, 2, 1};
+  ConvPlan p = conv_make_plan(g);
+  const size_t wb = align_up(p.packed_bytes, 256), abb = align_up(2 * 48 * sizeof(float), 256);
+  std::vector<char> host(2 * (wb + abb), 0);
+  const void* ws[2] = {w1_host, w2_host};
+  const float* al[2] = {alpha1, alpha2};
+  const float* be[2] = {beta1, beta2};
+  for (int k = 0; k < 2; ++k) {
+    conv_pack_weights(g, p, ws[k], host.data() + k * (wb + abb));
+    float* ab = reinterpret_cast<float*>(host.data() + k * (wb + abb) + wb);
+    for (int c = 0; c < 48; ++c) { ab[c] = al[k][c]; ab[48 + c] = be[k][c]; }
+  }
+  char* dev = nullptr;
+  RTPE_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), host.size()));
+  hipError_t e = hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(dev); return hip_fail(e, "hipMemcpy", __FILE__, __LINE__); }
+  int rc = conv_block_launch(reinterpret_cast<const _Float16*>(x), 48, (size_t)N * H * W * 48 * 2,
+                             reinterpret_cast<_Float16*>(y), 48, reinterpret_cast<const _Float16*>(dev),
+                             reinterpret_cast<const float*>(dev + wb), reinterpret_cast<const _Float16*>(dev + wb + abb),
+                             reinterpret_cast<const float*>(dev + wb + abb + wb), N, H, W, s);
+  hipError_t es = hipStreamSynchronize(s);
+  hipFree(dev);
+  if (rc != RTPE_OK) return rc;
+  if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
+  return RTPE_OK;
+}
+
 extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
                                 const void* w_host, const float* alpha_host, const float* beta_host,
                                 int32_t cout, int32_t ksize, int32_t stride, int32_t flags, const void* res,
@@ -511,6 +585,11 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
   {
     auto it = h->tuned.find(std::make_tuple(N, H, W));
     if (it != h->tuned.end() && it->second[op * 4].nt) t = it->second[op * 4];
+  }
+  if (o.fuse) {                      // fused BasicBlock (conv_block.hip): 6x32 tiles, 5 + 3 pixel tiles per wave
+    out8[0] = 3; out8[1] = o.fuse == 1 ? 5 : 3; out8[2] = 4; out8[3] = 6; out8[4] = 32; out8[5] = 48; out8[6] = 1;
+    out8[7] = o.fuse == 1 ? -900001 : -900002;
+    return RTPE_OK;
   }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
   out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : (int32_t)t.lds_bytes;

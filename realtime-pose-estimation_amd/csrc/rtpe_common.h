@@ -124,6 +124,10 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
 bool conv_stream_supports(const ConvPlan& p);
 size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots);
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+// fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
+bool conv_block_supports(int cin, int cout, int H, int W);
+int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,
+                      const float* ab1, const _Float16* w2, const float* ab2, int N, int H, int W, hipStream_t s);
 
 // ---- elementwise / stem (elementwise.hip) ---------------------------------
 struct FuseArgs {

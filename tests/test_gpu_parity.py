@@ -537,3 +537,38 @@ def test_teacher_prediction_export_and_reader(nat, teacher, tmp_path):
     want = F.interpolate(refined[:1].cpu(), hw, mode="bilinear", align_corners=True)[0]
     assert torch.equal(t_hms.cpu(), want)
     assert tuple(t_ae.shape) == (17,) + hw
+
+
+# --------------------------------------------------------------------------- #
+# fused BasicBlock (conv_block.hip)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("case", [(2, 32, 48), (1, 23, 37), (8, 160, 160), (3, 6, 16), (5, 70, 100)],
+                         ids=lambda c: "block_n%d_%dx%d" % c)
+def test_fused_basicblock_equals_two_convs(nat, case):
+    """the fused kernel must be BIT-identical to conv+BN+ReLU followed by conv+BN+add+ReLU (same k order,
+    same rounding points), including image borders, partial tiles and several units per workgroup"""
+    N, H, W = case
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn(N, H, W, 48, generator=g).half()
+    ws = [((torch.rand(48, 48, 3, 3, generator=g) * 2 - 1) / (48 * 9) ** 0.5).half().contiguous().numpy() for _ in range(2)]
+    al = [(torch.rand(48, generator=g) * 0.4 + 0.8).numpy() for _ in range(2)]
+    be = [(torch.randn(48, generator=g) * 0.1).numpy() for _ in range(2)]
+    dev = torch.device("cuda:0")
+    xd = x.to(dev)
+    st = nat.stream_ptr(dev)
+    fpt = ctypes.POINTER(ctypes.c_float)
+    mid = torch.empty_like(xd)
+    ref = torch.empty_like(xd)
+    L = nat.lib()
+    nat.check(L.rtpe_conv2d_nhwc(xd.data_ptr(), N, H, W, 48, ws[0].ctypes.data, al[0].ctypes.data_as(fpt),
+                                 be[0].ctypes.data_as(fpt), 48, 3, 1, nat.F_RELU | nat.F_ROUND_CONV, None,
+                                 mid.data_ptr(), st))
+    nat.check(L.rtpe_conv2d_nhwc(mid.data_ptr(), N, H, W, 48, ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
+                                 be[1].ctypes.data_as(fpt), 48, 3, 1, nat.F_RELU | nat.F_ROUND_CONV, xd.data_ptr(),
+                                 ref.data_ptr(), st))
+    got = torch.full_like(xd, float("nan"))
+    nat.check(L.rtpe_basicblock_nhwc(xd.data_ptr(), N, H, W, ws[0].ctypes.data, al[0].ctypes.data_as(fpt),
+                                     be[0].ctypes.data_as(fpt), ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
+                                     be[1].ctypes.data_as(fpt), got.data_ptr(), st))
+    a, b = got.cpu().view(torch.int16), ref.cpu().view(torch.int16)
+    assert torch.equal(a, b), "%d of %d elements differ" % ((a != b).sum().item(), a.numel())
