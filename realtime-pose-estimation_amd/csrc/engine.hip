@@ -140,7 +140,7 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
   // BasicBlock fusion (conv_block.hip): conv 48->48 k3 s1 +relu, then conv 48->48 k3 s1 +residual(+relu)
   // whose residual is the first conv's input and whose input is read by nobody else
   static const int fuse_blocks = getenv("RTPE_FUSE_BLOCKS") ? atoi(getenv("RTPE_FUSE_BLOCKS")) : 1;
-  for (size_t i = 0; fuse_blocks && i + 1 < h->ops.size(); ++i) {
+  for (size_t i = 0; fuse_blocks && i + 2 < h->ops.size(); ++i) {     // (the last op keeps its own event)
     OpState& a1 = h->ops[i];
     OpState& a2 = h->ops[i + 1];
     const rtpe_op_desc& d1 = a1.d;
@@ -398,12 +398,20 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       rc = fuse_launch(a, s);
     }
     if (rc != RTPE_OK) return rc;
-    if (timed) RTPE_HIP_CHECK(hipEventRecord(ev[i + 1], s));
-    if (rec) RTPE_HIP_CHECK(hipEventRecord((*rec)[i + 1], s));
+    // an op that was absorbed by the fused launch of its predecessor gets no event of its own (an empty
+    // event pair costs a few microseconds on the stream): its boundary is its predecessor's, its time 0
+    const bool absorbed = o.fuse == 2 && force == nullptr && only_op < 0;
+    if (timed && !absorbed) RTPE_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+    if (rec && !absorbed) RTPE_HIP_CHECK(hipEventRecord((*rec)[i + 1], s));
   }
   if (timed) {
     RTPE_HIP_CHECK(hipEventSynchronize(ev.back()));
-    for (size_t i = 0; i < h->ops.size(); ++i) RTPE_HIP_CHECK(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+      const bool absorbed = h->ops[i].fuse == 2 && force == nullptr && only_op < 0;
+      const size_t b0 = (i > 0 && h->ops[i - 1].fuse == 2 && force == nullptr && only_op < 0) ? i - 1 : i;
+      if (absorbed) op_ms[i] = 0.f;
+      else RTPE_HIP_CHECK(hipEventElapsedTime(&op_ms[i], ev[b0], ev[i + 1]));
+    }
     for (auto& e : ev) hipEventDestroy(e);
   }
   return RTPE_OK;
@@ -695,7 +703,10 @@ extern "C" int rtpe_hrnet_read_record(rtpe_hrnet* h, int32_t slot, float* op_ms,
   RTPE_REQUIRE(it != h->records.end() && it->second.size() == h->ops.size() + 1 && n_ops >= (int)h->ops.size(),
                "read_record: nothing recorded in slot %d", slot);
   RTPE_HIP_CHECK(hipEventSynchronize(it->second.back()));
-  for (size_t i = 0; i < h->ops.size(); ++i)
-    RTPE_HIP_CHECK(hipEventElapsedTime(&op_ms[i], it->second[i], it->second[i + 1]));
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    if (h->ops[i].fuse == 2) { op_ms[i] = 0.f; continue; }           // absorbed by the fused launch before it
+    const size_t b0 = (i > 0 && h->ops[i - 1].fuse == 2) ? i - 1 : i;
+    RTPE_HIP_CHECK(hipEventElapsedTime(&op_ms[i], it->second[b0], it->second[i + 1]));
+  }
   return RTPE_OK;
 }
