@@ -463,9 +463,10 @@ extern "C" int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, in
   const bool dc = d.kind == RTPE_OP_DECONV;
   const double po = dc ? pi * 4 : pi / (d.stride * d.stride);
   const double taps = dc ? 4 : d.ksize * d.ksize;
+  const double es = (d.flags & RTPE_F_F32) ? 4.0 : 2.0;       // bytes per element of this op's tensors
   *flops = 2.0 * po * d.cout * cin_logical * taps;
-  *bytes = pi * cin_logical * 2 + po * d.cout * 2 + (d.res_t >= 0 ? po * d.cout * 2 : 0) +
-           (double)cin_logical * d.cout * d.ksize * d.ksize * 2;
+  *bytes = pi * cin_logical * es + po * d.cout * es + (d.res_t >= 0 ? po * d.cout * es : 0) +
+           (double)cin_logical * d.cout * d.ksize * d.ksize * es;
   return RTPE_OK;
 }
 
