@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--weights", default="W0", choices=["W0", "W1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--dump-ops", default="", help="write the per-op table to this file")
     return ap.parse_args()
 
