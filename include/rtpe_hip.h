@@ -200,6 +200,19 @@ int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t W, const v
                          const float* alpha1, const float* beta1, const void* w2_host,
                          const float* alpha2, const float* beta2, void* y, void* stream);
 
+/* ConvTranspose2d(k=4, s=2, p=1, no bias) + BatchNorm (+ReLU), pose_higher_hrnet.py:513-524, as the
+ * four sub-pixel 2x2 convolutions the executor runs.  x NHWC fp16 (N,H,W,cin); w_host the PyTorch
+ * (cin, cout, 4, 4) fp16 weight; y NHWC fp16 (N,2H,2W,cout).  Host-returning (layer-level tests). */
+int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin, const void* w_host,
+                          const float* alpha_host, const float* beta_host, int32_t cout, int32_t flags,
+                          void* y, void* stream);
+
+/* HighResolutionModule fuse sum, pose_higher_hrnet.py:245-254: y = [relu](((t0 + t1) + t2) + ...) with one
+ * rounding per add; term t is a dense NHWC (N, H >> up[t], W >> up[t], C) tensor read with nearest
+ * upsampling (nn.Upsample :209).  flags: RTPE_F_RELU, RTPE_F_F32.  Stream-ordered. */
+int rtpe_fuse_nhwc(const void* const* terms, const int32_t* term_up, int32_t n_terms, int32_t N, int32_t H,
+                   int32_t W, int32_t C, int32_t flags, void* y, void* stream);
+
 /* NHWC fp16 conv: y = act( round16( round16?(conv(x,w)) * alpha + beta ) [+ res] ).
  * w: HOST pointer, fp16 OIHW (cout,cin,k,k); alpha/beta: HOST fp32[cout].
  * x:(N,H,W,cin) y:(N,Ho,Wo,cout) res:(N,Ho,Wo,cout) or NULL, device, dense.

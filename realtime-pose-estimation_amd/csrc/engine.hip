@@ -571,6 +571,71 @@ extern "C" int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t
   return RTPE_OK;
 }
 
+extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
+                                     const void* w_host, const float* alpha_host, const float* beta_host,
+                                     int32_t cout, int32_t flags, void* y, void* stream) {
+  RTPE_REQUIRE(x && w_host && alpha_host && beta_host && y, "deconv4x4s2_nhwc: null argument");
+  RTPE_REQUIRE(cin % 8 == 0 && cout % 8 == 0 && N > 0 && H > 0 && W > 0, "deconv4x4s2_nhwc: cin=%d cout=%d", cin, cout);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = RTPE_OK;
+  std::vector<char*> dev_bufs;
+  for (int k = 0; k < 4 && rc == RTPE_OK; ++k) {         // the four sub-pixel (parity) classes of the output
+    ConvGeom g{cin, cout, 4, 2, k, 2, 1};
+    ConvPlan p = conv_make_plan(g);
+    std::vector<char> packed(p.packed_bytes);
+    conv_pack_weights(g, p, w_host, packed.data());
+    std::vector<float> ab(2 * p.cout_pad, 0.f);
+    for (int c = 0; c < cout; ++c) { ab[c] = alpha_host[c]; ab[p.cout_pad + c] = beta_host[c]; }
+    char* dev = nullptr;
+    const size_t wb = align_up(p.packed_bytes, 256);
+    RTPE_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), wb + ab.size() * 4));
+    dev_bufs.push_back(dev);
+    hipError_t e = hipMemcpy(dev, packed.data(), p.packed_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dev + wb, ab.data(), ab.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__); break; }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = reinterpret_cast<const _Float16*>(x); a.in_ld = cin;
+    a.x_bytes = (size_t)N * H * W * cin * 2;
+    a.w = reinterpret_cast<const _Float16*>(dev);
+    a.alpha = reinterpret_cast<const float*>(dev + wb); a.beta = a.alpha + p.cout_pad;
+    a.y = reinterpret_cast<_Float16*>(y); a.out_ld = cout; a.cout_store = cout;
+    a.N = N; a.H_in = H; a.W_in = W;
+    a.H_full = 2 * H; a.W_full = 2 * W;
+    a.H_pos = H; a.W_pos = W; a.o_mul = 2; a.oy_add = k >> 1; a.ox_add = k & 1;
+    a.relu = (flags & RTPE_F_RELU) ? 1 : 0;
+    a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
+    const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos);
+    conv_fill_args(g, p, tile, &a);
+    rc = conv_launch(p, tile, a, s);
+  }
+  hipError_t es = hipStreamSynchronize(s);
+  for (char* d : dev_bufs) hipFree(d);
+  if (rc != RTPE_OK) return rc;
+  if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_fuse_nhwc(const void* const* terms, const int32_t* term_up, int32_t n_terms, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t flags, void* y, void* stream) {
+  RTPE_REQUIRE(terms && term_up && y && n_terms >= 1 && n_terms <= 4, "fuse_nhwc: bad argument");
+  FuseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_terms = n_terms;
+  for (int t = 0; t < n_terms; ++t) {
+    RTPE_REQUIRE(terms[t] != nullptr && term_up[t] >= 0 && term_up[t] < 8 && H % (1 << term_up[t]) == 0 &&
+                     W % (1 << term_up[t]) == 0, "fuse_nhwc: term %d", t);
+    a.term[t] = reinterpret_cast<const _Float16*>(terms[t]);
+    a.term_ld[t] = C;
+    a.term_up[t] = term_up[t];
+  }
+  a.y = reinterpret_cast<_Float16*>(y);
+  a.out_ld = C; a.C = C; a.N = N; a.H = H; a.W = W;
+  a.f32 = (flags & RTPE_F_F32) ? 1 : 0;
+  a.relu = (flags & RTPE_F_RELU) ? 1 : 0;
+  return fuse_launch(a, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int rtpe_conv2d_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
                                 const void* w_host, const float* alpha_host, const float* beta_host,
                                 int32_t cout, int32_t ksize, int32_t stride, int32_t flags, const void* res,

@@ -60,6 +60,10 @@ _SIGS = {
     "rtpe_conv2d_nhwc_ex": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                       POINTER(c_float), POINTER(c_float), c_int32, c_int32, c_int32,
                                       c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rtpe_deconv4x4s2_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(c_float),
+                                        POINTER(c_float), c_int32, c_int32, c_void_p, c_void_p]),
+    "rtpe_fuse_nhwc": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_int32, c_void_p, c_void_p]),
     "rtpe_basicblock_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(c_float), POINTER(c_float),
                                        c_void_p, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p]),
     "rtpe_warp_normalize": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),

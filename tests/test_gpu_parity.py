@@ -572,3 +572,58 @@ def test_fused_basicblock_equals_two_convs(nat, case):
                                      be[1].ctypes.data_as(fpt), got.data_ptr(), st))
     a, b = got.cpu().view(torch.int16), ref.cpu().view(torch.int16)
     assert torch.equal(a, b), "%d of %d elements differ" % ((a != b).sum().item(), a.numel())
+
+
+# --------------------------------------------------------------------------- #
+# layer-level entries for the remaining op kinds: transposed conv, fuse sum
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("case", [(96, 48, 20, 28, True), (48, 48, 16, 16, False)], ids=lambda c: "deconv_%d-%d_%dx%d" % c[:4])
+def test_deconv_layer(nat, case):
+    """ConvTranspose2d(k4 s2 p1) + BN + ReLU (pose_higher_hrnet.py:513-524) as four parity-class convs"""
+    cin, cout, H, W, relu = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    N = 2
+    x = torch.randn(N, cin, H, W, generator=g).half()
+    w = ((torch.rand(cin, cout, 4, 4, generator=g) * 2 - 1) / (cin * 4) ** 0.5).half()
+    alpha = torch.rand(cout, generator=g) * 0.4 + 0.8
+    beta = torch.randn(cout, generator=g) * 0.1
+    y = F.conv_transpose2d(x.float(), w.float(), None, 2, 1).half()
+    y = (y.double() * alpha.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)).float().half()
+    if relu:
+        y = F.relu(y)
+    dev = torch.device("cuda:0")
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    yd = torch.empty((N, 2 * H, 2 * W, cout), dtype=torch.float16, device=dev)
+    fpt = ctypes.POINTER(ctypes.c_float)
+    wn, a_np, b_np = w.contiguous().numpy(), alpha.numpy(), beta.numpy()
+    nat.check(nat.lib().rtpe_deconv4x4s2_nhwc(xd.data_ptr(), N, H, W, cin, wn.ctypes.data, a_np.ctypes.data_as(fpt),
+                                              b_np.ctypes.data_as(fpt), cout,
+                                              (nat.F_RELU if relu else 0) | nat.F_ROUND_CONV, yd.data_ptr(),
+                                              nat.stream_ptr(dev)))
+    got = yd.cpu().permute(0, 3, 1, 2).contiguous().numpy()
+    want = y.numpy()
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want.astype(np.float32)), 0.25))) - 10)
+    err = np.abs(got.astype(np.float32) - want.astype(np.float32)) / ulp
+    assert err.max() <= 2.0 and (got == want).mean() > 0.97, (err.max(), (got == want).mean())
+
+
+def test_fuse_layer(nat):
+    """the fuse sum with nearest-upsampled lower-resolution terms: bit-exact (fp16 adds in the module's order)"""
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 2, 24, 40, 48
+    ups = [0, 1, 2, 3]
+    terms = [torch.randn(N, H >> u, W >> u, C, generator=g).half() for u in ups]
+    want = terms[0].clone()
+    for t, u in zip(terms[1:], ups[1:]):
+        up = t.permute(0, 3, 1, 2).float()
+        up = F.interpolate(up, scale_factor=2 ** u, mode="nearest").half().permute(0, 2, 3, 1)
+        want = want + up                                      # one fp16 rounding per add, :250-253
+    want = F.relu(want)
+    dev = torch.device("cuda:0")
+    td = [t.to(dev) for t in terms]
+    yd = torch.empty((N, H, W, C), dtype=torch.float16, device=dev)
+    ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in td])
+    upa = (ctypes.c_int32 * 4)(*ups)
+    nat.check(nat.lib().rtpe_fuse_nhwc(ptrs, upa, 4, N, H, W, C, nat.F_RELU, yd.data_ptr(), nat.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    assert torch.equal(yd.cpu().view(torch.int16), want.contiguous().view(torch.int16))
