@@ -382,9 +382,7 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
     if (!p.cc) p.cc = round_up(cin8 < 128 ? cin8 : 64, 16);
   } else {
     if (cin8 % 48 == 0) p.cc = 48;
-    // stride 2 stages a (2 th + 1) x (2 tw + 1) halo: 32-channel chunks (96-B pixels, 9 exact k-steps
-    // per chunk) keep two workgroups per CU where 64-channel chunks (160-B pixels) leave one
-    else if (cin8 % 64 == 0) p.cc = (!dc && g.stride == 2) ? 32 : 64;
+    else if (cin8 % 64 == 0) p.cc = 64;
     else if (cin8 % 32 == 0) p.cc = 32;
     else p.cc = round_up(cin8 < 64 ? cin8 : 48, 16);
   }
