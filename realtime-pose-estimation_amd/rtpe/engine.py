@@ -29,7 +29,8 @@ def eval_student(model, hm_parser, val_dataloader, device,
 
     Each batch is a tuple whose first two items are ``(img_id, img)``.  ``model``
     may return one tensor (heatmaps in channels [:17], tags in [17:], as the
-    reference's students did) or the teacher's ``[preds, refined]`` list.
+    reference's students did), the teacher's ``[preds, refined]`` list, or the
+    dual-head student's ``(att, det)`` tuple (config 5).
     Plotting / image saving (``plot_every`` / ``save_every``) are not part of
     the accelerated path and are ignored.
     """
@@ -44,7 +45,15 @@ def eval_student(model, hm_parser, val_dataloader, device,
                 pred = model(img, out_hw)
             except TypeError:
                 pred = model(img)
-        if isinstance(pred, (list, tuple)):
+        if isinstance(pred, (list, tuple)) and pred[0].shape[1] == 1:
+            # dual-head student (rtpe/students.py:724-771): (attention mask, det) with the heat maps in
+            # det[:, :17] and the tags in det[:, 17:18], both at 1/4 resolution; decoded like the teacher's
+            # maps (validate_hhrnet.py:93-101): bilinear to the image size, then parse
+            det = pred[1].float()
+            res = hm_parser.parse_lowres(det[:, :NUM_HEATMAPS].contiguous(), det[:, NUM_HEATMAPS:NUM_HEATMAPS + 1]
+                                         .expand(-1, NUM_HEATMAPS, -1, -1).contiguous(), out_hw)
+            grouped, scores = [res[0][0]], res[0][1]
+        elif isinstance(pred, (list, tuple)):
             preds, refined = pred
             res = hm_parser.parse_lowres(refined.float(), preds[:, NUM_HEATMAPS:].float(), out_hw)
             grouped, scores = [res[0][0]], res[0][1]

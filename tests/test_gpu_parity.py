@@ -659,3 +659,41 @@ def test_block_fusion_does_not_change_the_network_output(nat, teacher, tmp_path)
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
+
+
+def test_eval_student_with_the_dual_head_student(nat, golden_dir):
+    """config 5 end to end: AttentionStudent -> (att, det) -> eval_student decodes det (17 heat maps + one shared
+    tag map) like validate_hhrnet.py:93-101; keypoints must equal the oracle's decode of the same det maps"""
+    import json
+    from rtpe import engine
+    from rtpe.students import AttentionStudent
+    from rtpe.third_party.group import HeatmapParser
+    shapes = json.load(open(os.path.join(golden_dir, "student_shapes.json")))["shapes"]
+    sd = synth.make_state_dict({k: tuple(v) for k, v in shapes.items()}, 3, "W1")
+    stu = AttentionStudent(None, "cpu", 100, 17, 1, True, None, False).eval()
+    stu.load_state_dict(sd, strict=True)
+    stu = stu.to("cuda:0")
+    imgs = [synth.make_images(1, 96, 128, seed=s) for s in (1, 2)]
+    loader = [(i, im) for i, im in enumerate(imgs)]
+    parser = HeatmapParser(num_joints=17, **engine.HM_PARSER_PARAMS)
+    seen = []
+    orig = parser.parse_lowres
+
+    def spy(hm, tg, hw, *a, **k):
+        res = orig(hm, tg, hw, *a, **k)
+        seen.append((hm.cpu(), tg.cpu(), hw, res))
+        return res
+    parser.parse_lowres = spy
+    out = engine.eval_student(stu, parser, loader, "cuda:0")
+    assert out["images"] == 2 and len(seen) == 2
+    for hm, tg, hw, res in seen:
+        assert hm.shape == (1, 17, 24, 32) and tg.shape == (1, 17, 24, 32) and hw == (96, 128)
+        assert torch.equal(tg[:, 0], tg[:, 5])                         # one tag map, shared by all joints
+        hms = decode_ref.upsample_bilinear(hm, *hw)
+        aes = decode_ref.upsample_bilinear(tg, *hw)
+        want, wsc = decode_ref.HeatmapParserRef().parse(hms, aes.unsqueeze(-1))
+        got, gsc = res[0]
+        want0 = want[0] if len(want) and np.size(want[0]) else np.zeros((0, 17, 4), np.float32)
+        got0 = got if got.ndim == 3 else np.zeros((0, 17, 4), np.float32)
+        assert got0.shape == want0.shape and np.array_equal(got0, want0)
+        assert [float(v) for v in gsc] == [float(v) for v in wsc]
