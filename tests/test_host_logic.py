@@ -266,3 +266,25 @@ def test_teacher_prediction_files(built, tmp_path):
     np.testing.assert_array_equal(t_ae.numpy(), preds[0, 17:])
     with pytest.raises(ValueError):
         engine.save_teacher_predictions(base, preds[:, :30], refined)
+
+
+def test_checkpoint_loading_paths(built, w48_shapes, tmp_path):
+    """the reference's loading entry points on a checkpoint file with the upstream key layout (``1.`` prefix):
+    get_hrnet_w48_teacher (helpers.py:32-73), StemHRNet.load_pretrained / get_pretrained_stem
+    (students.py:262-298) and AttentionStudent(hhrnet_statedict_path=...) (students.py:601-640)"""
+    from rtpe.helpers import get_hrnet_w48_teacher
+    from rtpe.students import AttentionStudent, get_pretrained_stem
+    sd = synth.make_state_dict(w48_shapes, 0, "W1")
+    path = str(tmp_path / "pose_higher_hrnet_w48_640.pth.tar")
+    torch.save({"1." + k: v for k, v in sd.items()}, path)
+    teacher = get_hrnet_w48_teacher(path)
+    assert not teacher.training and teacher[1].conv1.weight.dtype == torch.float16
+    assert torch.equal(teacher[1].bn1.running_mean, sd["bn1.running_mean"])
+    assert torch.equal(teacher[1].conv1.weight, sd["conv1.weight"].half())
+    stem = get_pretrained_stem(path, "cpu", True)
+    assert torch.equal(stem[1].layer1[3].bn3.weight, sd["layer1.3.bn3.weight"])
+    assert torch.equal(stem[1].layer1[0].downsample[0].weight, sd["layer1.0.downsample.0.weight"].half())
+    stu = AttentionStudent(path, "cpu", 48, 17, 1, True, None, False)
+    assert torch.equal(stu.stem[1].conv2.weight, sd["conv2.weight"].half())
+    prog = stu.compile_program()
+    assert prog.n_preds == 1 and prog.n_refined == 18
