@@ -697,3 +697,22 @@ def test_eval_student_with_the_dual_head_student(nat, golden_dir):
         got0 = got if got.ndim == 3 else np.zeros((0, 17, 4), np.float32)
         assert got0.shape == want0.shape and np.array_equal(got0, want0)
         assert [float(v) for v in gsc] == [float(v) for v in wsc]
+
+
+@pytest.mark.parametrize("inplanes,half", [(48, True), (64, False)], ids=lambda v: str(v))
+def test_student_other_widths_vs_oracle(nat, inplanes, half):
+    """AttentionStudent at its default width (48) and with an fp32 stem, against the oracle restatement"""
+    from oracle import student_ref
+    from rtpe.students import AttentionStudent
+    stu = AttentionStudent(None, "cpu", inplanes, 17, 1, half, None, False).eval()
+    shapes = {k: tuple(v.shape) for k, v in stu.state_dict().items()}
+    sd = synth.make_state_dict(shapes, 5, "W1")
+    stu.load_state_dict(sd, strict=True)
+    stu = stu.to("cuda:0")
+    x = synth.make_images(2, 128, 160, seed=9)
+    oa, od = student_ref.student_forward(sd, x, half_stem=half)
+    with torch.no_grad():
+        att, det = stu(x.to("cuda:0"))
+    ea, ed = (att.cpu() - oa).abs().max().item(), (det.cpu() - od).abs().max().item()
+    print("student inplanes=%d half=%s: att %.3e det %.3e" % (inplanes, half, ea, ed))
+    assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
