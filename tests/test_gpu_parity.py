@@ -716,3 +716,23 @@ def test_student_other_widths_vs_oracle(nat, inplanes, half):
     ea, ed = (att.cpu() - oa).abs().max().item(), (det.cpu() - od).abs().max().item()
     print("student inplanes=%d half=%s: att %.3e det %.3e" % (inplanes, half, ea, ed))
     assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
+
+
+def test_other_constructor_configuration_vs_oracle(nat):
+    """the network class is not hard-wired to the w48 checkpoint: fewer modules / blocks (constructor arguments of
+    pose_higher_hrnet.py:266-287) compile and run the same way; checked against the functional oracle in fp32"""
+    from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+    torch.manual_seed(3)
+    net = PoseHigherResolutionNet(s3_modules=1, s4_modules=2, s2_blocks=[2, 2], s3_blocks=[2, 2, 2],
+                                  s4_blocks=[2, 2, 2, 2], deconv_num_blocks=2).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.make_state_dict(shapes, 1, "W1")
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0")
+    x = synth.make_images(1, 96, 160, seed=4)
+    with torch.no_grad():
+        preds, refined = net(x.to("cuda:0"))
+    op, orf = hrnet_ref.hrnet_forward(sd, x, half=False)
+    e1, e2 = (preds.cpu() - op).abs().max().item(), (refined.cpu() - orf).abs().max().item()
+    print("reduced configuration fp32: preds %.2e refined %.2e" % (e1, e2))
+    assert preds.shape == (1, 34, 24, 40) and refined.shape == (1, 17, 48, 80) and e1 <= 2e-4 and e2 <= 2e-4
