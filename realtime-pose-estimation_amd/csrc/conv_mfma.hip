@@ -446,8 +446,12 @@ static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
 // streaming kernel (conv_stream.hip): one workgroup per CU, 3-slot weight ring + 2-3 halo buffers
 static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, ConvTile* out,
                         bool allow_resident = true) {
-  if (!conv_stream_supports(p) || (c.nt != 4 && c.nt != 5) || c.tw > 40) return false;
-  const int hh = c.th + 2, hw = c.tw + 2;
+  // stride 1: 4 or 5 pixel tiles per wave; stride 2 (4x the halo per output pixel): 2, and only with
+  // resident weights (the halo buffers leave no room for the weight ring)
+  if (!conv_stream_supports(p)) return false;
+  if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != 2 || p.n_cchunks != 1)) return false;
+  const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
+  if (hw * 6 > 256) return false;                        // a halo row is at most 4 DMA instructions
   const size_t in_tile = (size_t)hh * hw * p.pstride;
   const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
   size_t buf = in_tile > out_tile ? in_tile : out_tile;
@@ -488,7 +492,8 @@ static ConvTile make_stream_tile(const ConvPlan& p, int N, int H_pos, int W_pos)
     const long units = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N * p.n_cb;
     const double rounds = (double)units / t.grid;
     const double imbalance = rounds >= 1.0 ? (double)((long)(rounds + 0.999)) / rounds : 1.0;
-    const double halo = (double)(c.th + 2) * (c.tw + 2) / ((double)c.th * c.tw);
+    const double halo = (double)((c.th - 1) * p.in_mul + 3) * ((c.tw - 1) * p.in_mul + 3) /
+                        ((double)c.th * c.tw * p.in_mul * p.in_mul);
     // 5 MFMA waves leave one SIMD with two of them; resident weights save the per-stage weight stream
     const double score = waste * imbalance * (1.0 + 0.15 * (halo - 1.0)) * (t.n_bufs == 3 ? 1.0 : 1.05) *
                          (c.waves == 5 ? 1.3 : 1.0) * (t.n_wslots == 3 ? 1.0 : 0.8);

@@ -1,6 +1,8 @@
 // Streaming implicit-GEMM 3x3 convolution for the 48-channel-chunked layers of the
 // w48 network (Cin in {48, 96, 192, 384}, stride 1: every BasicBlock conv, i.e. ~85 %
-// of the forward FLOPs; pose_higher_hrnet.py:46-75 of the reference).  Same math, same
+// of the forward FLOPs; pose_higher_hrnet.py:46-75 of the reference; and the stride-2
+// convs of the fuse layers with Cin = 48, :213-230, whose (2 th + 1) x (2 tw + 1) halo
+// tiles still fit twice beside the resident weights).  Same math, same
 // k order, same epilogue rounding points and the same packed-weight format as
 // conv_mfma.hip, so results are bit-identical; what changes is how operands reach the
 // MFMAs.  Measured on the one-workgroup-per-tile kernel: every layer class sat at
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
       t -= n * tiles_xy;
       const uint32_t tyi = fdiv(t, a.div_tiles_x);
       const uint32_t txi = t - tyi * a.tiles_x;
-      const int iy0 = (int)tyi * a.th + a.lo_y, ix0 = (int)txi * a.tw + a.lo_x;
+      const int iy0 = (int)tyi * a.th * a.in_mul + a.lo_y, ix0 = (int)txi * a.tw * a.in_mul + a.lo_x;
       // per-lane column part of the address, one value per DMA instruction of a row
       uint32_t voff[4];
 #pragma unroll
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
     const uint32_t p = (wv * NT + nt) * 16 + r;
     const uint32_t oy = fdiv(p, a.div_tw);
     const uint32_t ox = p - oy * a.tw;
-    pixbase[nt] = (int)((oy * a.halo_w + ox) * kPStride);
+    pixbase[nt] = (int)((oy * a.in_mul * a.halo_w + ox * a.in_mul) * kPStride);   // in_mul = conv stride
   }
   constexpr int ROWB = MT * 32 + 16;
   constexpr int CH = MT * 2;
@@ -552,7 +554,7 @@ size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslot
 
 bool conv_stream_supports(const ConvPlan& p) {
   return p.esize == 2 && p.dil == 1 && p.cc == kCC && p.pstride == kPStride && p.tapw == 3 && p.kc == kKC &&
-         p.in_mul == 1 && p.mt <= 3 && (p.n_cchunks & (p.n_cchunks - 1)) == 0;
+         (p.in_mul == 1 || p.in_mul == 2) && p.mt <= 3 && (p.n_cchunks & (p.n_cchunks - 1)) == 0;
 }
 
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
@@ -570,7 +572,7 @@ int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, 
                (size_t)t.waves * t.nt * 16 * (p.mt * 32 + 16) <= (size_t)t.buf_bytes, "streaming conv: tile buffer too small");
 #define RTPE_S(MTv, NTv, Wv) \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_stream<MTv, NTv, Wv>(t, a, s);
-  RTPE_S(3, 4, 4) RTPE_S(3, 5, 4) RTPE_S(3, 5, 5)
+  RTPE_S(3, 4, 4) RTPE_S(3, 5, 4) RTPE_S(3, 5, 5) RTPE_S(3, 2, 4)
   RTPE_S(2, 4, 4) RTPE_S(2, 5, 4) RTPE_S(2, 5, 5)
   RTPE_S(1, 4, 4) RTPE_S(1, 5, 4) RTPE_S(1, 5, 5)
 #undef RTPE_S
