@@ -46,6 +46,7 @@ constexpr int kWSlot = kMT * kKH * 1024;         // 21,504 B
 constexpr int kXBytes = kXH * kXW * kPS;         // 34,560 B
 constexpr int kMidBytes = kMH * kMW * kPS;       // 26,112 B
 constexpr int kRowB = kMT * 32 + 16;             // transposed output row in LDS
+constexpr int kNIT = (kNT2 * 16 * 6 + 63) / 64;  // 16-byte output row pieces per lane in epilogue B
 constexpr int kLds = 3 * kWSlot + 2 * kXBytes + kMidBytes;
 
 #define RTPE_BBARRIER()                         \
@@ -70,6 +71,7 @@ struct BlockArgs {
   int tiles_x, tiles_y;
   FastDiv div_tiles_x, div_tiles_xy;
   int x_bytes;
+  int stagger;              // diagnostic (RTPE_BLOCK_STAGGER): every other workgroup starts this many kilocycles late
 };
 
 __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const BlockArgs a) {
@@ -222,6 +224,25 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
 #pragma unroll
   for (int m = 0; m < kMT; ++m) asm volatile("" ::"v"(al1[m]), "v"(be1[m]), "v"(al2[m]), "v"(be2[m]));
 
+  // epilogue B, 16-byte row piece `it` of this lane (fixed for the whole kernel): where it is in the
+  // wave's transposed slab (eoff) and in the x tile (xoff, the residual), and its position in the output
+  // tile (epos = row << 16 | column << 8 | byte offset in the pixel; a piece that does not exist gets a
+  // row no tile reaches)
+  int eoff[kNIT], xoff[kNIT], epos[kNIT];
+#pragma unroll
+  for (int it = 0; it < kNIT; ++it) {
+    int c = it * 64 + lane;
+    const bool exists = c < kNT2 * 16 * 6;
+    c = exists ? c : 0;
+    const int pw = c / 6, slot = c - pw * 6;
+    const int p = wv * kNT2 * 16 + pw;
+    const int oy = p >> 5, ox = p & 31;
+    eoff[it] = pw * kRowB + slot * 16;
+    xoff[it] = ((oy + 2) * kXW + ox + 2) * kPS + slot * 16;
+    epos[it] = ((exists ? oy : 0x7fff) << 16) | (ox << 8) | (slot * 16);
+  }
+  if (a.stagger && (jw & 1))
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   int wsel = 0;                                          // ring slot of the next half stage (q % 3)
   for (int u = 0; u < U; ++u) {
     uint32_t n;
@@ -365,29 +386,27 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
           const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
           *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
         }
-      constexpr int NIT = (kNT2 * 16 * 6 + 63) / 64;     // 16-byte row pieces per lane
-      half8 ov[NIT], rv[NIT];
+      half8 ov[kNIT], rv[kNIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        int c = it * 64 + lane_e;
-        c = c < kNT2 * 16 * 6 ? c : 0;
-        const int pw = c / 6, slot = c - pw * 6;
-        const int p = wv * kNT2 * 16 + pw;
-        const int oy = p >> 5, ox = p & 31;
-        ov[it] = *reinterpret_cast<const half8*>(obuf + pw * kRowB + slot * 16);
-        rv[it] = *reinterpret_cast<const half8*>(xb + ((oy + 2) * kXW + ox + 2) * kPS + slot * 16);   // the block input
+      for (int it = 0; it < kNIT; ++it) {
+        ov[it] = *reinterpret_cast<const half8*>(obuf + eoff[it]);
+        rv[it] = *reinterpret_cast<const half8*>(xb + xoff[it]);                            // the block input
       }
+      // scalar base of the unit + 32-bit lane offset (two 24-bit multiply-adds per piece)
+      const int hy = a.H - py0, hx = a.W - px0;
+      char* const yb = reinterpret_cast<char*>(a.y + (((size_t)n * a.H + py0) * a.W + px0) * a.out_ld);
+      const uint32_t ld2 = (uint32_t)a.out_ld * 2u, row_pix = (uint32_t)a.W & 0xffffffu;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int c = it * 64 + lane_e;
-        const int pw = c / 6, slot = c - pw * 6;
-        const int p = wv * kNT2 * 16 + pw;
-        const int py = py0 + (p >> 5), px = px0 + (p & 31);
+      for (int it = 0; it < kNIT; ++it) {
+        int e = epos[it];
+        asm volatile("" : "+v"(e));                      // lane-only math must not be hoisted out of the unit loop
         half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
         short8 b = __builtin_bit_cast(short8, v);
         b = b & ~(b >> 15);
-        if (c < kNT2 * 16 * 6 && py < a.H && px < a.W)
-          *reinterpret_cast<short8*>(a.y + (((size_t)n * a.H + py) * a.W + px) * a.out_ld + slot * 8) = b;
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx) {
+          const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
+          *reinterpret_cast<short8*>(yb + __umul24(pix, ld2) + ((uint32_t)e & 255u)) = b;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -417,6 +436,8 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   a.div_tiles_x = make_fastdiv(a.tiles_x);
   a.div_tiles_xy = make_fastdiv(a.tiles_x * a.tiles_y);
   a.x_bytes = (int)x_bytes;
+  static const int stagger = getenv("RTPE_BLOCK_STAGGER") ? atoi(getenv("RTPE_BLOCK_STAGGER")) : 0;
+  a.stagger = stagger;
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
   long G = 32;                                            // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;

@@ -38,6 +38,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef short short8 __attribute__((ext_vector_type(8)));
+typedef int int4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -105,8 +106,28 @@ struct Units {
 
 }  // namespace
 
+// The residual row pieces of the next unit are in flight while the k-loop runs.  They live in a fixed
+// register window v[224:255] that the compiler never allocates (amdgpu_num_vgpr below): the loads and
+// the adds name the registers in their asm text.  An asm OUTPUT operand would be an ordinary value to
+// the register allocator, which is free to copy it (live-range splitting, loop-carried values) right
+// after the load was issued, i.e. before the data has arrived.
+constexpr int kResReg0 = 224;
+#define RTPE_RES_LOAD(K, R0, R1, R2, R3)                                                             \
+  if (it == K)                                                                                       \
+    asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, %1" ::"v"(off), "s"(rb)               \
+                 : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);
+#define RTPE_RES_ADD(K, R0, R1, R2, R3)                                                              \
+  if (it == K)                                                                                       \
+    asm volatile("v_pk_add_f16 %0, %0, v" #R0 "\n\tv_pk_add_f16 %1, %1, v" #R1 "\n\tv_pk_add_f16 %2, %2, v" #R2 \
+                 "\n\tv_pk_add_f16 %3, %3, v" #R3                                                   \
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#define RTPE_RES_ALL(X)                                                                              \
+  X(0, 224, 225, 226, 227) X(1, 228, 229, 230, 231) X(2, 232, 233, 234, 235) X(3, 236, 237, 238, 239) \
+  X(4, 240, 241, 242, 243) X(5, 244, 245, 246, 247) X(6, 248, 249, 250, 251) X(7, 252, 253, 254, 255)
+
 template <int MT, int NT, int WAVES>
-__global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__((WAVES + kLoaders) * 64) __attribute__((amdgpu_num_vgpr(kResReg0)))
+conv_stream_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WSLOT = MT * kKH * 1024;               // weight fragments of one half stage
   char* const wring = smem;
@@ -290,9 +311,12 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
   constexpr int ROWB = MT * 32 + 16;
   constexpr int CH = MT * 2;
   constexpr int NIT = (NT * 16 * CH + 63) / 64;          // 16-byte row pieces per lane in the epilogue
-  // row piece `it` of this lane: pixel of the wave's slab, 16-byte slot, position in the tile
-  // (valid bit in the sign): fixed for the whole kernel
-  int edesc[NIT];
+  // row piece `it` of this lane, fixed for the whole kernel: its 16 bytes in the wave's transposed slab
+  // (eoff) and its position (epos = row << 16 | column * o_mul << 8 | 16-byte slot * 16; a piece that
+  // does not exist or lies in the channel padding gets a row no tile reaches).  Per unit only a scalar
+  // base address, two compares and two 24-bit multiply-adds per piece are left; stores and residual
+  // loads use the scalar-base + 32-bit-lane-offset form
+  int eoff[NIT], epos[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int c = it * 64 + lane;
@@ -300,8 +324,14 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
     const uint32_t p = wv * NT * 16 + pw;
     const uint32_t oyt = fdiv(p, a.div_tw);
     const uint32_t oxt = p - oyt * a.tw;
-    edesc[it] = c < NT * 16 * CH ? (int)((pw << 16) | (slot << 12) | (oyt << 6) | oxt) : -1;
+    eoff[it] = c < NT * 16 * CH ? pw * ROWB + slot * 16 : 0;
+    epos[it] = (int)((oyt << 16) | ((oxt * a.o_mul) << 8) | (slot * 16));
   }
+  const uint32_t row_pix = (uint32_t)(a.W_full * a.o_mul) & 0xffffffu;   // pixels between two tile rows
+  auto piece_off = [&](int e, uint32_t ld2) __attribute__((always_inline)) {
+    const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
+    return __umul24(pix, ld2) + ((uint32_t)e & 255u);
+  };
 
   float4v acc[MT][NT];
   int bsel = 0;                                          // s % NB
@@ -325,7 +355,17 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
   for (int m = 0; m < MT; ++m)                           // read them here: the compiler's wait for these
     asm volatile("" ::"v"(al[m]), "v"(be[m]));           // loads belongs in front of the unit loop
   const int cblk = cb0 * MT * 16;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    const int slot = c % CH;
+    if (c >= NT * 16 * CH || cblk + slot * 8 >= a.cout_store) epos[it] |= 0x7fff0000;
+  }
   const bool use_res = a.res != nullptr && !(a.ablate & 2);
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long st[16] = {0};
+  const unsigned long long k_begin = __builtin_readcyclecounter();
+#endif
 
   // one half stage: 7 k-steps, operands of step k+1 are requested before the MFMAs of step k
   auto half_stage = [&](const char* wslot, const char* tilebuf, auto hsel) {
@@ -380,31 +420,35 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
     q.px0 = (int)txi * a.tw;
     return q;
   };
-  // residual rows of unit u into one of the two register sets; they are requested TWO units
-  // before they are added, so an HBM round trip and the write acknowledgements queued in front
-  // of them (vmcnt completes in order) are off the critical path
-  // The loads are issued from inline asm: the compiler's own s_waitcnt insertion cannot follow a
-  // register set that is filled two units before it is read and answered with vmcnt(0) after
-  // every store; here the one wait that is needed is written by hand (run_unit).  Every lane
-  // loads (lanes without a valid row piece read the first row of the tensor and never store).
-  auto load_res = [&](int u, half8 (&rr)[NIT]) {
+  // residual rows of unit u: requested ONE unit ahead (right after the previous unit's rows were
+  // added, before its stores), so an HBM round trip and the write acknowledgements queued in front
+  // of them (vmcnt completes in order) have a whole k-loop to finish.  The loads are issued from
+  // inline asm: the compiler's own s_waitcnt insertion answers a register set that is filled one unit
+  // before it is read with vmcnt(0) after every store; here the one wait that is needed is written by
+  // hand (run_unit).  One register set and ONE copy of the unit code: the unrolled unit is ~35 KiB of
+  // instructions, two alternating copies did not fit the 64 KiB instruction cache two CUs share.
+  // Every lane loads (lanes without a valid row piece read the unit's first pixel and never store).
+  static_assert(NIT <= 8, "residual register window");
+  auto load_res = [&](int u) {
     const UnitPos q = unit_pos(u);
+    const int hy = a.H_pos - q.py0, hx = (a.W_pos - q.px0) * a.o_mul;
+    const size_t pix0 = ((size_t)q.n * a.H_full + q.py0 * a.o_mul + a.oy_add) * a.W_full + q.px0 * a.o_mul + a.ox_add;
+    const _Float16* rb = a.res + pix0 * a.res_ld + cblk;
+    const uint32_t ld2 = (uint32_t)a.res_ld * 2u;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      int d = edesc[it];
-      asm volatile("" : "+v"(d));                        // lane-only math must not be hoisted out of the unit loop
-      const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7;
-      const int py = q.py0 + oyt, px = q.px0 + oxt;
-      const int ch = cblk + slot * 8;
-      const bool ok = d >= 0 && py < a.H_pos && px < a.W_pos && ch < a.cout_store;
-      const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
-      const size_t off = ok ? (((size_t)q.n * a.H_full + oy) * a.W_full + ox) * a.res_ld + ch : 0;
-      const _Float16* ptr = a.res + off;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[it]) : "v"(ptr) : "memory");
+      int e = epos[it];
+      asm volatile("" : "+v"(e));                        // lane-only math must not be hoisted out of the unit loop
+      const bool ok = (e >> 16) < hy && ((e >> 8) & 255) < hx;
+      const uint32_t off = ok ? piece_off(e, ld2) : 0u;   // the unit's first pixel is always inside the tensor
+      RTPE_RES_ALL(RTPE_RES_LOAD)
     }
   };
 
-  auto run_unit = [&](int u, half8 (&rr)[NIT]) {
+  auto run_unit = [&](int u) {
+#ifdef RTPE_CONV_STAMPS
+    unsigned long long m0, m1, m2, m3, m4;
+#endif
     const UnitPos q = unit_pos(u);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -415,10 +459,18 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
       tilebuf = tiles + bsel * a.buf_bytes;
       const int w0 = resident ? 2 * cci : wsel;
       const int w1 = resident ? 2 * cci + 1 : (wsel == 2 ? 0 : wsel + 1);
+      SSTAMP(m0);
       RTPE_SBARRIER();                                   // M(s): tile s and weight half 2s are in LDS
+      SSTAMP(m1);
       if (!(a.ablate & 1)) half_stage(wring + w0 * WSLOT, tilebuf, std::integral_constant<int, 0>());
+      SSTAMP(m2);
       if (!resident) RTPE_SBARRIER();                    // H(s): weight half 2s+1 is in LDS
+      SSTAMP(m3);
       if (!(a.ablate & 1)) half_stage(wring + w1 * WSLOT, tilebuf, std::integral_constant<int, 1>());
+      SSTAMP(m4);
+#ifdef RTPE_CONV_STAMPS
+      st[0] += m1 - m0; st[1] += m2 - m1; st[2] += m3 - m2; st[3] += m4 - m3; st[5] += 1;
+#endif
       if (cci + 1 < ncc) {
         bsel = bsel + 1 == NB ? 0 : bsel + 1;
         wsel = wsel == 0 ? 2 : wsel - 1;                 // (2 (s+1)) % 3 = (wsel + 2) % 3
@@ -429,11 +481,13 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
     asm volatile("" : "+v"(lane_e));                     // as above: keep the epilogue's lane math in the loop
     const int re = lane_e & 15, ge = lane_e >> 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SSTAMP(m0);
     RTPE_SBARRIER();                                     // E(s): every MFMA wave is done with the tile
+    SSTAMP(m1);
     char* obuf = tilebuf + wv * (NT * 16 * ROWB);
     // BN / bias with the wrapper's rounding points, two channels per VALU op where the ISA allows it
-    auto bn_to_lds = [&](auto rc) {
-      constexpr bool RC = decltype(rc)::value;
+    auto bn_to_lds = [&](auto rc, auto nchw) {
+      constexpr bool RC = decltype(rc)::value, NCHW = decltype(nchw)::value;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -449,7 +503,7 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
           const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
           const half4 o{olo[0], olo[1], ohi[0], ohi[1]};
           *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * ROWB + m * 32 + ge * 8) = o;
-          if (a.y_nchw != nullptr) {                     // heads: NCHW straight from the registers
+          if (NCHW) {                                    // heads: NCHW straight from the registers
             const uint32_t p = (wv * NT + nt) * 16 + re;
             const uint32_t oyt = fdiv(p, a.div_tw);
             const uint32_t oxt = p - oyt * a.tw;
@@ -475,61 +529,71 @@ __global__ void __launch_bounds__((WAVES + kLoaders) * 64) conv_stream_kernel(co
         }
       }
     };
-    if (a.round_conv) bn_to_lds(std::true_type()); else bn_to_lds(std::false_type());
+    // the executed variant is one straight run of instructions (instruction cache, see load_res)
+    if (a.y_nchw != nullptr) {
+      if (a.round_conv) bn_to_lds(std::true_type(), std::true_type()); else bn_to_lds(std::false_type(), std::true_type());
+    } else {
+      if (a.round_conv) bn_to_lds(std::true_type(), std::false_type()); else bn_to_lds(std::false_type(), std::false_type());
+    }
+    SSTAMP(m2);
     if (a.y != nullptr && !(a.ablate & 2)) {
-      // the residual rows of THIS unit have landed: vmcnt completes in order and the only vector
-      // memory operations this wave is sure to have issued after them are the NIT loads of the
-      // next unit's rows (plus stores, which may then be older or newer: waiting for them is safe)
-      if (use_res) {
-        if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // the residual rows of THIS unit were requested a k-loop ago; nothing newer than the stores
+      // that followed them is outstanding
+      if (use_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SSTAMP(m3);
       // all row pieces are read from LDS first (no control flow between the reads), then
       // finished and stored: one LDS latency per unit instead of one per piece
       half8 ov[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        int d = edesc[it] & 0x7fffffff;
-        asm volatile("" : "+v"(d));
-        const int slot = (d >> 12) & 7, pw = (d >> 16) % (NT * 16);
-        ov[it] = *reinterpret_cast<const half8*>(obuf + pw * ROWB + slot * 16);
-      }
+      for (int it = 0; it < NIT; ++it) ov[it] = *reinterpret_cast<const half8*>(obuf + eoff[it]);
+      const int hy = a.H_pos - q.py0, hx = (a.W_pos - q.px0) * a.o_mul;
+      const size_t pix0 = ((size_t)q.n * a.H_full + q.py0 * a.o_mul + a.oy_add) * a.W_full + q.px0 * a.o_mul + a.ox_add;
+      char* const yb = reinterpret_cast<char*>(a.y + pix0 * a.out_ld + cblk);
+      const uint32_t ld2 = (uint32_t)a.out_ld * 2u;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        int d = edesc[it];
-        asm volatile("" : "+v"(d));
-        const int oxt = d & 63, oyt = (d >> 6) & 63, slot = (d >> 12) & 7;
-        const int py = q.py0 + oyt, px = q.px0 + oxt;
-        const int ch = cblk + slot * 8;
-        half8 v = ov[it];
-        if (use_res) v = v + rr[it];                     // fp16 add, round-to-nearest-even = the wrapper's add
+        if (use_res) {                                   // fp16 add, round-to-nearest-even = the wrapper's add
+          int4v w = __builtin_bit_cast(int4v, ov[it]);
+          RTPE_RES_ALL(RTPE_RES_ADD)
+          ov[it] = __builtin_bit_cast(half8, w);
+        }
         if (a.relu) {                                    // x > 0 ? x : +0, on the sign bits
-          short8 b = __builtin_bit_cast(short8, v);
+          short8 b = __builtin_bit_cast(short8, ov[it]);
           b = b & ~(b >> 15);
-          v = __builtin_bit_cast(half8, b);
+          ov[it] = __builtin_bit_cast(half8, b);
         }
-        if (d >= 0 && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
-          const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
-          const size_t pix = ((size_t)q.n * a.H_full + oy) * a.W_full + ox;
-          *reinterpret_cast<half8*>(a.y + pix * a.out_ld + ch) = v;
-        }
+      }
+      if (use_res && u + 1 < n_units) load_res(u + 1);   // the adds are done: the window is free
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int e = epos[it];
+        asm volatile("" : "+v"(e));
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx) *reinterpret_cast<half8*>(yb + piece_off(e, ld2)) = ov[it];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS traffic on the buffer is over
-    if (use_res && u + 2 < n_units) load_res(u + 2, rr);   // this register set is free again
+    SSTAMP(m4);
+#ifdef RTPE_CONV_STAMPS
+    { unsigned long long m5; SSTAMP(m5);
+      st[12] += m1 - m0; st[13] += m2 - m1; st[4] += m3 - m2; st[14] += m4 - m3; st[10] += m5 - m4; }
+#endif
     bsel = bsel + 1 == NB ? 0 : bsel + 1;
     wsel = wsel == 0 ? 2 : wsel - 1;
   };
 
-  half8 rres_a[NIT], rres_b[NIT];
-  if (use_res) {
-    load_res(0, rres_a);
-    if (n_units > 1) load_res(1, rres_b);
+  // diagnostic (RTPE_STREAM_ABL >> 8): every other workgroup of an XCD starts late, so that the
+  // store bursts of the CUs do not coincide
+  if ((a.ablate >> 8) && ((blockIdx.x >> 3) & 1))
+    for (int i = 0; i < (a.ablate >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+  if (use_res) load_res(0);
+  for (int u = 0; u < n_units; ++u) run_unit(u);
+#ifdef RTPE_CONV_STAMPS
+  if (a.dbg != nullptr && lane == 0) {
+    st[15] = __builtin_readcyclecounter() - k_begin;
+    const int slots[] = {0, 1, 2, 3, 4, 5, 10, 12, 13, 14, 15};
+    for (int i : slots) atomicAdd(&a.dbg[i], st[i]);
   }
-  for (int u = 0; u < n_units; u += 2) {
-    run_unit(u, rres_a);
-    if (u + 1 < n_units) run_unit(u + 1, rres_b);
-  }
+#endif
 }
 
 template <int MT, int NT, int WAVES>

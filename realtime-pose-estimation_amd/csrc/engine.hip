@@ -520,15 +520,19 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   unsigned long long hd[16];
   hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost);
   hipFree(dbg);
-  if (tile.kind == 2 && hd[5] && (hd[11] = hd[11] ? hd[11] : hd[5] / tile.waves))
-    fprintf(stderr, "stream conv %dx%d nt%d w%d nb%d nw%d grid %d | per MFMA-wave stage: waitM %llu half0 %llu waitH %llu half1 %llu "
-            "setup %llu E-wait %llu transpose %llu add+store %llu | weight loader/stage: wait %llu issue %llu | tile loaders/stage: wait %llu issue %llu\n",
-            tile.th, tile.tw, tile.nt, tile.waves, tile.n_bufs, tile.n_wslots, tile.grid, hd[0] / hd[5], hd[1] / hd[5], hd[2] / hd[5],
-            hd[3] / hd[5], hd[4] / hd[5], hd[12] / hd[5], hd[13] / hd[5], hd[14] / hd[5], hd[6] / hd[11], hd[7] / hd[11], hd[8] / hd[11], hd[9] / hd[11]);
+  if (tile.kind == 2 && hd[5] && (hd[11] = hd[11] ? hd[11] : hd[5] / tile.waves)) {
+    const unsigned long long nw = (unsigned long long)tile.grid * tile.waves, units = hd[5] / p.n_cchunks;
+    fprintf(stderr, "stream conv %dx%d nt%d w%d nb%d nw%d grid %d | per MFMA wave: total %llu cycles, %llu units | per stage: waitM %llu half0 %llu "
+            "waitH %llu half1 %llu | per unit: E-wait %llu bn+transpose %llu res-wait %llu rows+add+store %llu load_res %llu | weight loader/stage: wait %llu issue %llu | "
+            "tile loaders/stage: wait %llu issue %llu\n",
+            tile.th, tile.tw, tile.nt, tile.waves, tile.n_bufs, tile.n_wslots, tile.grid, hd[15] / nw, units / nw, hd[0] / hd[5], hd[1] / hd[5],
+            hd[2] / hd[5], hd[3] / hd[5], hd[12] / units, hd[13] / units, hd[4] / units, hd[14] / units, hd[10] / units, hd[6] / hd[11],
+            hd[7] / hd[11], hd[8] / hd[11], hd[9] / hd[11]);
+  }
   else if (hd[5])
     fprintf(stderr, "conv stamps (kind %d): n %llu | per wave(-unit) cycles: setup %llu stage/wait1 %llu kloop %llu epilogue %llu total/wait2 %llu\n",
             tile.kind, hd[5], hd[0] / hd[5], hd[1] / hd[5], hd[2] / hd[5], hd[3] / hd[5], hd[4] / hd[5]);
-  if (hd[10])
+  if (hd[10] && tile.kind != 2)
     fprintf(stderr, "   loader per stage: vmcnt-wait %llu barrier1 %llu issue %llu barriersE+2 %llu (stages %llu)\n",
             hd[6] / hd[10], hd[7] / hd[10], hd[8] / hd[10], hd[9] / hd[10], hd[10]);
 #endif
