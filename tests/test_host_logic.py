@@ -288,3 +288,32 @@ def test_checkpoint_loading_paths(built, w48_shapes, tmp_path):
     assert torch.equal(stu.stem[1].conv2.weight, sd["conv2.weight"].half())
     prog = stu.compile_program()
     assert prog.n_preds == 1 and prog.n_refined == 18
+
+
+def test_stream_kernel_register_window_is_not_allocated(built, tmp_path):
+    """conv_stream.hip keeps the residual rows that are in flight in v[224:255] and names those registers
+    in its asm text; `amdgpu_num_vgpr(224)` is a target for the register allocator, not a hard limit, so a
+    change that raises the pressure would let compiler temporaries land in the window (silent corruption).
+    The device code of the built object must touch v224+ only through the three hand-written forms."""
+    import re
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    obj = os.path.join(os.path.dirname(built.LIB_PATH), "build", "conv_stream.hip.o")
+    fat, co = str(tmp_path / "s.fatbin"), str(tmp_path / "s.co")
+    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+    subprocess.run([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--input=" + fat, "--output=" + co], check=True)
+    dis = subprocess.run([llvm + "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    mine = re.compile(r"global_load_dwordx4 v\[2\d\d:2\d\d\], v\d+, s\[|v_pk_add_f16 v\d+, v\d+, v2\d\d\b")
+    n_window = 0
+    for line in dis.splitlines():
+        code = line.split("//")[0]
+        hi = 0
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", code):
+            hi = max(hi, int(m.group(2)))
+        for m in re.finditer(r"\bv(\d+)\b", code):
+            hi = max(hi, int(m.group(1)))
+        if hi >= 224:
+            assert mine.search(code), "compiler-allocated register in the window: " + code.strip()
+            n_window += 1
+    assert n_window > 0
