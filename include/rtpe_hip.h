@@ -165,6 +165,13 @@ int rtpe_hrnet_forward_record(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                               void* workspace, size_t workspace_bytes, void* stream, int32_t slot);
 int rtpe_hrnet_read_record(rtpe_hrnet* h, int32_t slot, float* op_ms, int32_t n_ops);
 
+/* number of activation tensors a forward of (N,H,W) keeps plane-major
+ * ([C/48][N][H][W][48]) instead of NHWC: the inner tensors of the BasicBlock
+ * chains with C >= 96 (pose_higher_hrnet.py:46-75) when every conv around them
+ * runs on the streaming kernel.  Internal layout only, results are identical
+ * (RTPE_PLANE_MAJOR=0 turns it off). */
+int rtpe_hrnet_plane_major_tensors(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, int32_t* count);
+
 /* algorithmic cost of op i for (N,H,W): flops and HBM bytes of a layer-fused
  * execution (SURVEY.md section 8d accounting). */
 int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W,

@@ -558,6 +558,9 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->div_tiles_x = make_fastdiv(a->tiles_x);
   a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
   a->n_cb = p.n_cb;
+  if (a->in_cs == 0) a->in_cs = p.cc;
+  if (a->out_cs == 0) a->out_cs = p.mt * 16;
+  if (a->res_cs == 0) a->res_cs = p.mt * 16;
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
@@ -633,6 +636,8 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 2) return conv_stream_launch(p, t, a, s);
+  RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
+               "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");
 #define RTPE_V(MTv, NTv, Wv)                                                                  \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv)                                            \
     return p.esize == 4 ? launch_variant<float, MTv, NTv, Wv>(t, a, p.n_cb, s)                 \

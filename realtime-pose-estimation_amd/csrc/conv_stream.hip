@@ -216,7 +216,9 @@ conv_stream_kernel(const ConvArgs a) {
     auto issue = [&](int s, int r0, int r1) {           // halo rows [r0, r1) of the tile of stage s
       int tile, cb;
       um.get(s >> sh, &tile, &cb);
-      const int cbase = (s & (ncc - 1)) * kCC;
+      const int chunk = s & (ncc - 1);
+      const int cbase = chunk * kCC;
+      const int chunk_off = (int)(chunk * a.in_cs);       // elements: 48 per chunk (NHWC) or one plane
       uint32_t t = (uint32_t)tile;
       const uint32_t n = fdiv(t, a.div_tiles_xy);
       t -= n * tiles_xy;
@@ -231,14 +233,14 @@ conv_stream_kernel(const ConvArgs a) {
         const int hx = q / kSlots, sl = q - hx * kSlots;
         const int ix = ix0 + hx;
         const bool ok = (unsigned)ix < (unsigned)a.W_in && cbase + sl * 8 < a.cin;
-        voff[k] = ok ? (uint32_t)(ix * a.in_ld + cbase + sl * 8) * 2u : 0x80000000u;
+        voff[k] = ok ? (uint32_t)(ix * a.in_ld + sl * 8) * 2u : 0x80000000u;
       }
       char* buf = tiles + (s % NB) * a.buf_bytes;
       const int img_row0 = (int)n * a.H_in;
       for (int r = r0; r < r1; ++r) {
         const int iy = iy0 + r;
         const bool row_ok = (unsigned)iy < (unsigned)a.H_in;
-        const int soff = row_ok ? (img_row0 + iy) * a.W_in * a.in_ld * 2 : 0;
+        const int soff = row_ok ? ((img_row0 + iy) * a.W_in * a.in_ld + chunk_off) * 2 : 0;
         char* dst = buf + r * rowbytes;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -433,7 +435,7 @@ conv_stream_kernel(const ConvArgs a) {
     const UnitPos q = unit_pos(u);
     const int hy = a.H_pos - q.py0, hx = (a.W_pos - q.px0) * a.o_mul;
     const size_t pix0 = ((size_t)q.n * a.H_full + q.py0 * a.o_mul + a.oy_add) * a.W_full + q.px0 * a.o_mul + a.ox_add;
-    const _Float16* rb = a.res + pix0 * a.res_ld + cblk;
+    const _Float16* rb = a.res + pix0 * a.res_ld + (size_t)cb0 * a.res_cs;
     const uint32_t ld2 = (uint32_t)a.res_ld * 2u;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -548,7 +550,7 @@ conv_stream_kernel(const ConvArgs a) {
       for (int it = 0; it < NIT; ++it) ov[it] = *reinterpret_cast<const half8*>(obuf + eoff[it]);
       const int hy = a.H_pos - q.py0, hx = (a.W_pos - q.px0) * a.o_mul;
       const size_t pix0 = ((size_t)q.n * a.H_full + q.py0 * a.o_mul + a.oy_add) * a.W_full + q.px0 * a.o_mul + a.ox_add;
-      char* const yb = reinterpret_cast<char*>(a.y + pix0 * a.out_ld + cblk);
+      char* const yb = reinterpret_cast<char*>(a.y + pix0 * a.out_ld + (size_t)cb0 * a.out_cs);
       const uint32_t ld2 = (uint32_t)a.out_ld * 2u;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -624,7 +626,8 @@ bool conv_stream_supports(const ConvPlan& p) {
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
   RTPE_REQUIRE(conv_stream_supports(p), "streaming conv: unsupported plan");
   RTPE_REQUIRE(a.x_bytes > 0 && a.x_bytes < 0x80000000ull, "streaming conv: input view of %zu bytes", (size_t)a.x_bytes);
-  RTPE_REQUIRE(a.cin % 8 == 0 && a.in_ld >= a.cin, "streaming conv: cin=%d in_ld=%d", a.cin, a.in_ld);
+  RTPE_REQUIRE(a.cin % 8 == 0 && (a.in_cs == kCC ? a.in_ld >= a.cin : a.in_ld == kCC),
+               "streaming conv: cin=%d in_ld=%d chunk stride %lld", a.cin, a.in_ld, a.in_cs);
   RTPE_REQUIRE(t.grid >= 8 && t.grid % 8 == 0 && (t.grid / 8) % p.n_cb == 0, "streaming conv: bad grid %d", t.grid);
   RTPE_REQUIRE((t.n_bufs == 2 || t.n_bufs == 3) && t.buf_bytes % 16 == 0 &&
                (t.n_wslots == 3 || t.n_wslots == 2 * p.n_cchunks) &&

@@ -48,6 +48,11 @@ struct rtpe_hrnet {
   std::map<std::tuple<int, int, int>, std::vector<ConvTile>> tuned;
   std::map<int, std::vector<hipEvent_t>> records;   // per-op events of rtpe_hrnet_forward_record, by slot
   std::vector<rtpe_tensor_desc> tensors;
+  // tensors that MAY be kept plane-major ([C/48][N][H][W][48] instead of NHWC): C >= 96 and every op that
+  // touches them is a 3x3 stride-1 conv the streaming kernel runs (the inner tensors of a BasicBlock chain).
+  // A 48-channel block is then one contiguous row per image row instead of 96 bytes of every 2C: the
+  // kernel's stores, residual loads and halo DMA move whole cache lines.  Decided per run (see run()).
+  std::vector<char> plane_ok;
   int n_slots;
   char* arena;        // device: packed weights + affine params
   size_t arena_bytes;
@@ -164,6 +169,32 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     a2.fuse = 2;
   }
   h->arena_bytes = off;
+  {
+    static const int plane_major = getenv("RTPE_PLANE_MAJOR") ? atoi(getenv("RTPE_PLANE_MAJOR")) : 1;
+    h->plane_ok.assign(h->tensors.size(), 0);
+    for (size_t t = 0; plane_major && t < h->tensors.size(); ++t) {
+      const rtpe_tensor_desc& td = h->tensors[t];
+      if (td.reserved == 4 || td.channels < 96 || td.channels % 48 != 0) continue;
+      bool ok = true, touched = false;
+      for (const OpState& o : h->ops) {
+        const rtpe_op_desc& d = o.d;
+        bool uses = d.in_t == (int)t || d.out_t == (int)t || d.res_t == (int)t;
+        for (int k = 0; k < d.n_terms; ++k) uses |= d.term_t[k] == (int)t;
+        if (!uses) continue;
+        touched = true;
+        const int clean = RTPE_F_RELU | RTPE_F_ROUND_CONV;
+        if (d.kind != RTPE_OP_CONV || o.n_geom != 1 || d.n_terms != 0 || (d.flags & ~clean) || d.ksize != 3 ||
+            d.stride != 1 || !conv_stream_supports(o.plan[0]) || o.plan[0].mt != 3 || d.cout % 48 != 0 ||
+            d.in_coff != 0 || d.out_coff != 0 || (d.res_t >= 0 && d.res_coff != 0) || d.reserved[2] != 0 ||
+            d.cin != h->tensors[d.in_t].channels || d.cout != h->tensors[d.out_t].channels ||
+            (d.res_t >= 0 && h->tensors[d.res_t].channels != d.cout)) {
+          ok = false;
+          break;
+        }
+      }
+      h->plane_ok[t] = ok && touched;
+    }
+  }
 
   // pass 2: pack on the host, one upload
   std::vector<char> host(off, 0);
@@ -230,6 +261,37 @@ extern "C" int rtpe_hrnet_workspace_bytes(const rtpe_hrnet* h, int32_t N, int32_
   return RTPE_OK;
 }
 
+// plane-major tensors of one run: the candidates all of whose ops run on the streaming kernel with the launch
+// shapes in force (tiny maps fall back to the generic kernel, which only knows NHWC)
+static std::vector<char> plane_tensors(const rtpe_hrnet* h, int N, int H, int W, const std::vector<ConvTile>* tuned) {
+  std::vector<char> plane = h->plane_ok;
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const OpState& o = h->ops[i];
+    const rtpe_op_desc& d = o.d;
+    if (d.kind != RTPE_OP_CONV || o.n_geom != 1) continue;
+    if (!(plane[d.in_t] || plane[d.out_t] || (d.res_t >= 0 && plane[d.res_t]))) continue;
+    const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+    const ConvTile t = (tuned && (*tuned)[i * 4].nt) ? (*tuned)[i * 4]
+                                                      : conv_make_tile(o.plan[0], N, H >> ti.ds_log2, W >> ti.ds_log2);
+    if (t.kind != 2) {
+      plane[d.in_t] = plane[d.out_t] = 0;
+      if (d.res_t >= 0) plane[d.res_t] = 0;
+    }
+  }
+  return plane;
+}
+
+extern "C" int rtpe_hrnet_plane_major_tensors(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, int32_t* count) {
+  RTPE_REQUIRE(h != nullptr && count != nullptr, "plane_major_tensors: null argument");
+  const std::vector<ConvTile>* tuned = nullptr;
+  auto it = h->tuned.find(std::make_tuple((int)N, (int)H, (int)W));
+  if (it != h->tuned.end()) tuned = &it->second;
+  int n = 0;
+  for (char c : plane_tensors(h, N, H, W, tuned)) n += c;
+  *count = n;
+  return RTPE_OK;
+}
+
 static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
                int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms,
                int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
@@ -269,6 +331,8 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     auto it = h->tuned.find(std::make_tuple(N, H, W));
     if (it != h->tuned.end()) tuned = &it->second;
   }
+  std::vector<char> plane(h->tensors.size(), 0);
+  if (only_op < 0 && force == nullptr) plane = plane_tensors(h, N, H, W, tuned);
   for (size_t i = 0; i < h->ops.size(); ++i) {
     if (only_op >= 0 && (int)i != only_op) continue;
     const OpState& o = h->ops[i];
@@ -310,14 +374,20 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         memset(&a, 0, sizeof(a));
         a.x = tptr(d.in_t, d.in_coff);
         a.in_ld = ti.channels;
+        if (plane[d.in_t]) { a.in_ld = 48; a.in_cs = (long long)N * Hi * Wi * 48; }
         a.x_bytes = ((size_t)N * Hi * Wi * ti.channels - (size_t)d.in_coff) * esz(d.in_t);
         a.w = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[k]);
         a.alpha = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
         a.beta = a.alpha + o.plan[0].cout_pad;
-        if (d.res_t >= 0) { a.res = tptr(d.res_t, d.res_coff); a.res_ld = h->tensors[d.res_t].channels; }
+        if (d.res_t >= 0) {
+          a.res = tptr(d.res_t, d.res_coff);
+          a.res_ld = h->tensors[d.res_t].channels;
+          if (plane[d.res_t]) { a.res_ld = 48; a.res_cs = (long long)N * Ho * Wo * 48; }
+        }
         if (!(d.flags & RTPE_F_NO_NHWC)) {
           a.y = tptr(d.out_t, d.out_coff);
           a.out_ld = h->tensors[d.out_t].channels;
+          if (plane[d.out_t]) { a.out_ld = 48; a.out_cs = (long long)N * Ho * Wo * 48; }
           // zero-padded channels up to the allocated row are written too (they
           // are exact zeros: zero weights, zero affine) so that a consumer that
           // reads the padded view sees finite data

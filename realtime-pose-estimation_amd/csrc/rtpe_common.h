@@ -59,6 +59,9 @@ struct ConvArgs {
   int o_mul, oy_add, ox_add;  // output pixel = pos * o_mul + add
   int in_mul;            // input base = pos * in_mul
   int out_ld, res_ld;
+  // element offset of 48-channel chunk c from a view's base: c * cs.  NHWC: cs = channels of a chunk, ld = channels
+  // of the tensor; plane-major [C/48][N][H][W][48] (streaming kernel only): cs = N*H*W*48, ld = 48.  0 = NHWC default
+  long long in_cs, out_cs, res_cs;
   int cin, cout;         // logical
   int cout_store;        // channels written to NHWC (multiple of 4 groups masked)
   int nchw_channels;     // channel count of the NCHW output

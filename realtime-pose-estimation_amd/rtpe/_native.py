@@ -54,6 +54,7 @@ _SIGS = {
     "rtpe_hrnet_autotune": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "rtpe_hrnet_op_tile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32)]),
+    "rtpe_hrnet_plane_major_tensors": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32)]),
     "rtpe_conv2d_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    POINTER(c_float), POINTER(c_float), c_int32, c_int32, c_int32,
                                    c_int32, c_void_p, c_void_p, c_void_p]),
