@@ -74,6 +74,8 @@ int fuse_launch(const FuseArgs& a, hipStream_t s) {
 constexpr int kStemTH = 8, kStemTW = 32, kStemCO = 64;
 constexpr int kStemPH = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 1;
 
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
 template <typename T>
 __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
   constexpr bool kHalf = sizeof(T) == 2;
@@ -105,45 +107,70 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
   }
   __syncthreads();
 
-  const int ly = tid / kStemTW, lx = tid % kStemTW;
-  const int oy = oy0 + ly, ox = ox0 + lx;
-  float acc[kStemCO];
+  // thread = 8 output pixels x 8 output channels.  Lane = (pixel group g = lane / 8, channel group lane % 8); a
+  // wave owns two tile rows (64 pixels), the thread's p-th pixel is number 8 p + g of them, so the 8 lanes of
+  // a pixel write its 128-byte NHWC row together and one store instruction covers 8 consecutive pixels = 1 KiB
+  // (a CU drains partial-line writes at ~2 B/clk: one pixel x 64 channels per thread, 16 bytes per lane at a
+  // 128-byte stride, ran the kernel at 1.7 TB/s).  A weight fragment read from LDS feeds 32 FMAs.  Same
+  // accumulation order per output (ky, kx, c), so the bits do not change.
+  const int lane = tid & 63, wv = tid >> 6;
+  const int cg = lane & 7, g = lane >> 3;
+  float acc[8][8];
 #pragma unroll
-  for (int co = 0; co < kStemCO; ++co) acc[co] = 0.f;
+  for (int p = 0; p < 8; ++p)
 #pragma unroll
+    for (int co = 0; co < 8; ++co) acc[p][co] = 0.f;
+  // (the tap loops stay loops: fully unrolled, the scheduler hoists every weight read and spills)
+#pragma unroll 1
   for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
+#pragma unroll 1
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float xv = patch[c][2 * ly + ky][2 * lx + kx];
-        const float4* wr = reinterpret_cast<const float4*>(wl[(ky * 3 + kx) * 3 + c]);
+        float xv[8];
 #pragma unroll
-        for (int q = 0; q < kStemCO / 4; ++q) {
-          const float4 w4 = wr[q];
-          acc[4 * q + 0] = __builtin_fmaf(xv, w4.x, acc[4 * q + 0]);
-          acc[4 * q + 1] = __builtin_fmaf(xv, w4.y, acc[4 * q + 1]);
-          acc[4 * q + 2] = __builtin_fmaf(xv, w4.z, acc[4 * q + 2]);
-          acc[4 * q + 3] = __builtin_fmaf(xv, w4.w, acc[4 * q + 3]);
+        for (int p = 0; p < 8; ++p) {
+          const int idx = p * 8 + g;
+          xv[p] = patch[c][2 * (2 * wv + (idx >> 5)) + ky][2 * (idx & 31) + kx];
+        }
+        const float4* wr = reinterpret_cast<const float4*>(&wl[(ky * 3 + kx) * 3 + c][cg * 8]);
+        const float4 w0 = wr[0], w1 = wr[1];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          acc[p][0] = __builtin_fmaf(xv[p], w0.x, acc[p][0]);
+          acc[p][1] = __builtin_fmaf(xv[p], w0.y, acc[p][1]);
+          acc[p][2] = __builtin_fmaf(xv[p], w0.z, acc[p][2]);
+          acc[p][3] = __builtin_fmaf(xv[p], w0.w, acc[p][3]);
+          acc[p][4] = __builtin_fmaf(xv[p], w1.x, acc[p][4]);
+          acc[p][5] = __builtin_fmaf(xv[p], w1.y, acc[p][5]);
+          acc[p][6] = __builtin_fmaf(xv[p], w1.z, acc[p][6]);
+          acc[p][7] = __builtin_fmaf(xv[p], w1.w, acc[p][7]);
         }
       }
-  if (oy < Ho && ox < Wo) {
-    T* dst = reinterpret_cast<T*>(a.y) + (((size_t)n * Ho + oy) * Wo + ox) * a.out_ld;
-    constexpr int EPS = 16 / (int)sizeof(T);
+  constexpr int EPS = 16 / (int)sizeof(T);
+  float al[8], be[8];
 #pragma unroll
-    for (int q = 0; q < kStemCO / EPS; ++q) {
+  for (int j = 0; j < 8; ++j) { al[j] = a.alpha[cg * 8 + j]; be[j] = a.beta[cg * 8 + j]; }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int idx = p * 8 + g;
+    const int oy = oy0 + 2 * wv + (idx >> 5), ox = ox0 + (idx & 31);
+    if (oy >= Ho || ox >= Wo) continue;
+    T* dst = reinterpret_cast<T*>(a.y) + (((size_t)n * Ho + oy) * Wo + ox) * a.out_ld + cg * 8;
+#pragma unroll
+    for (int q = 0; q < 8 / EPS; ++q) {
       T o[EPS];
 #pragma unroll
       for (int j = 0; j < EPS; ++j) {
         const int co = q * EPS + j;
-        float v = kHalf ? round16(acc[co]) : acc[co];                 // conv output
-        v = __builtin_fmaf(v, a.alpha[co], a.beta[co]);               // BN output
+        float v = kHalf ? round16(acc[p][co]) : acc[p][co];                          // conv output
+        v = __builtin_fmaf(v, al[co], be[co]);                                       // BN output
         if (kHalf) v = round16(v);
         o[j] = (T)(v > 0.f ? v : 0.f);
       }
-      uint4 raw;
+      uint4v raw;
       __builtin_memcpy(&raw, o, 16);
-      *reinterpret_cast<uint4*>(dst + q * EPS) = raw;
+      *reinterpret_cast<uint4v*>(dst + q * EPS) = raw;
     }
   }
 }
