@@ -42,6 +42,7 @@ def main():
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / 5 * 1e3
     names = list(eng.program.names)
+    print('plane-major inner tensors in this run: %d' % eng.plane_major_tensors(B, S, S), flush=True)
     by = {}
     for i, nm in enumerate(names):
         t = eng.op_tile(i, B, S, S)
