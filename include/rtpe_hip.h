@@ -330,6 +330,20 @@ int rtpe_adjust_refine_fused(const float* hm, int32_t hh, int32_t hw, int64_t hm
                              int32_t do_adjust, int32_t do_refine, float* scores,
                              void* scratch, size_t scratch_bytes, void* stream);
 
+/* The same for a caller that still holds the top-k table rtpe_topk_fused wrote
+ * for these maps (topk_val / topk_ind: (N*J, K), device-addressable): refine's
+ * exact arg-max shortcut needs the first pixel attaining each plane's maximum,
+ * which is the table's first entry whenever that maximum is positive, so the
+ * extra pass over every plane is skipped (group.py:202-264 semantics
+ * unchanged; planes without a positive maximum take the full scan). */
+int rtpe_adjust_refine_fused_topk(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
+                                  const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride,
+                                  int32_t N, int32_t J, int32_t oh, int32_t ow,
+                                  const float* ans_in, float* ans_out, const int32_t* person_img, int32_t P,
+                                  int32_t do_adjust, int32_t do_refine, float* scores,
+                                  const float* topk_val, const int32_t* topk_ind, int32_t K,
+                                  void* scratch, size_t scratch_bytes, void* stream);
+
 /* match_by_tag for a batch of N images on `n_threads` host threads.  Inputs as
  * rtpe_match_by_tag with a leading image axis.  People of image n follow those
  * of image n-1 in `ans` (max_people_total rows of (J,3+D)); person_img[i] =

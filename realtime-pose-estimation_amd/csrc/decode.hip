@@ -557,10 +557,12 @@ __device__ __forceinline__ void argmax_rows<BilinearMap>(const BilinearMap& m, i
 }
 
 template <class Map>
-__global__ void __launch_bounds__(256) plane_argmax_kernel(Map m, int h, int w, u64* plane_key, int lds_floats) {
+__global__ void __launch_bounds__(256) plane_argmax_kernel(Map m, int h, int w, u64* plane_key, int lds_floats,
+                                                           const unsigned char* known) {
   extern __shared__ __attribute__((aligned(16))) float argmax_src[];
   __shared__ u64 red[4];
   const int plane = blockIdx.y;
+  if (known != nullptr && known[plane]) return;            // its maximum came with the top-k table
   const int rows = (h + gridDim.x - 1) / gridDim.x;
   const int y_begin = blockIdx.x * rows, y_end = min(h, y_begin + rows);
   if (y_begin >= y_end) return;
@@ -569,6 +571,18 @@ __global__ void __launch_bounds__(256) plane_argmax_kernel(Map m, int h, int w, 
   argmax_rows(m, plane, w, y_begin, y_end, &bv, &bi, lds_floats > 0 ? argmax_src : nullptr, lds_floats);
   const u64 k = block_max(bi == 0xffffffffu ? 0 : make_key(bv, bi), red);
   if (threadIdx.x == 0 && k != 0) atomicMax(&plane_key[plane], k);
+}
+
+// the first pixel that attains a plane's maximum, taken from the top-k table of the same map (possibly in pinned
+// host memory: one read per plane here, not one per missing joint): its first entry - the best positive 5x5
+// local maximum, ties by lowest index - IS that pixel whenever the maximum is positive; otherwise 0 = full scan
+__global__ void __launch_bounds__(256) plane_key_from_topk_kernel(const float* topk_val, const int* topk_ind, int K,
+                                                                  int n_planes, u64* plane_key, unsigned char* known) {
+  const int plane = blockIdx.x * 256 + threadIdx.x;
+  if (plane >= n_planes) return;
+  const float v = topk_val[(size_t)plane * K];
+  plane_key[plane] = v > 0.f ? make_key(v, (unsigned)topk_ind[(size_t)plane * K]) : 0;
+  known[plane] = v > 0.f;                                  // the others (nowhere positive) still need the pass
 }
 
 template <class TagMap>
@@ -770,13 +784,14 @@ __global__ void __launch_bounds__(256) refine_finalize_kernel(Map m, int J, int 
 constexpr int kShortcutPlanes = 1 << 16;   // plane maxima kept for the arg-max shortcut (more planes: full scans only)
 static size_t refine_scratch(int P, int J, int D) {
   return (size_t)P * J * sizeof(u64) + (size_t)P * D * sizeof(float) + 256 + (size_t)kShortcutPlanes * sizeof(u64) +
-         (size_t)P * J;
+         (size_t)P * J + kShortcutPlanes;                  // + need_scan flags + per-plane "maximum known" flags
 }
 
 template <class Map, class TagMap>
 static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, int h, int w, int D,
                              const float* ans_in, float* ans_out, const int* person_img, int P, int do_adjust,
-                             int do_refine, float* scores, void* scratch, size_t scratch_bytes, hipStream_t s) {
+                             int do_refine, float* scores, void* scratch, size_t scratch_bytes, hipStream_t s,
+                             const float* topk_val = nullptr, const int* topk_ind = nullptr, int topk_k = 0) {
   RTPE_REQUIRE(scratch && scratch_bytes >= refine_scratch(P, J, D), "adjust_refine: scratch too small");
   u64* best_key = reinterpret_cast<u64*>(scratch);
   float* mean_tag = reinterpret_cast<float*>(best_key + (size_t)P * J);
@@ -790,9 +805,16 @@ static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, i
     char* tail = reinterpret_cast<char*>(mean_tag + (size_t)P * D);
     u64* plane_key = reinterpret_cast<u64*>(tail + ((256 - ((uintptr_t)tail & 255)) & 255));
     need_scan = reinterpret_cast<unsigned char*>(plane_key + kShortcutPlanes);
-    RTPE_HIP_CHECK(hipMemsetAsync(plane_key, 0, (size_t)n_img * J * sizeof(u64), s));
+    unsigned char* known = nullptr;
+    if (topk_val != nullptr) {
+      known = need_scan + (size_t)P * J;
+      hipLaunchKernelGGL(plane_key_from_topk_kernel, dim3((n_img * J + 255) / 256), dim3(256), 0, s, topk_val, topk_ind,
+                         topk_k, n_img * J, plane_key, known);
+    } else {
+      RTPE_HIP_CHECK(hipMemsetAsync(plane_key, 0, (size_t)n_img * J * sizeof(u64), s));
+    }
     hipLaunchKernelGGL((plane_argmax_kernel<Map>), dim3(kRefineStripes, n_img * J), dim3(256), 48 * 1024, s, m, h, w,
-                       plane_key, 48 * 1024 / 4);
+                       plane_key, 48 * 1024 / 4, known);
     RTPE_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((refine_shortcut_kernel<TagMap>), dim3((P * J + 255) / 256), dim3(256), 0, s, tm, J, w, D, ans_in,
                        person_img, P, mean_tag, plane_key, best_key, need_scan);
@@ -946,4 +968,20 @@ extern "C" int rtpe_adjust_refine_fused(const float* hm, int32_t hh, int32_t hw,
   BilinearTag tm{make_bilinear(tg, th, tw, tg_img_stride, J, oh, ow)};
   return adjust_refine_run(m, tm, N, J, oh, ow, 1, ans_in, ans_out, person_img, P, do_adjust, do_refine, scores,
                            scratch, scratch_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int rtpe_adjust_refine_fused_topk(const float* hm, int32_t hh, int32_t hw, int64_t hm_img_stride,
+                                             const float* tg, int32_t th, int32_t tw, int64_t tg_img_stride, int32_t N,
+                                             int32_t J, int32_t oh, int32_t ow, const float* ans_in, float* ans_out,
+                                             const int32_t* person_img, int32_t P, int32_t do_adjust,
+                                             int32_t do_refine, float* scores, const float* topk_val,
+                                             const int32_t* topk_ind, int32_t K, void* scratch, size_t scratch_bytes,
+                                             void* stream) {
+  RTPE_REQUIRE(hm && tg && ((ans_in && ans_out && ans_in != ans_out) || P == 0) && N > 0 && J > 0 && J <= kMaxJ &&
+               topk_val && topk_ind && K > 0, "adjust_refine_fused_topk: bad argument");
+  if (P <= 0) return RTPE_OK;
+  BilinearMap m = make_bilinear(hm, hh, hw, hm_img_stride, J, oh, ow);
+  BilinearTag tm{make_bilinear(tg, th, tw, tg_img_stride, J, oh, ow)};
+  return adjust_refine_run(m, tm, N, J, oh, ow, 1, ans_in, ans_out, person_img, P, do_adjust, do_refine, scores,
+                           scratch, scratch_bytes, reinterpret_cast<hipStream_t>(stream), topk_val, topk_ind, K);
 }

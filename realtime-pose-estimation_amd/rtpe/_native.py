@@ -91,6 +91,10 @@ _SIGS = {
                                            c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                            c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
                                            c_void_p]),
+    "rtpe_adjust_refine_fused_topk": (c_int32, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_int32, c_int32,
+                                                c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                                c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                                c_int32, c_void_p, c_size_t, c_void_p]),
     "rtpe_match_by_tag_batch": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_int32, c_double, c_double, c_int32, c_int32, c_void_p,
                                           c_int32, c_void_p, c_void_p, c_int32]),

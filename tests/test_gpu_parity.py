@@ -425,6 +425,29 @@ def test_parse_lowres_batch_equals_per_image_oracle(nat):
         np.testing.assert_array_equal(np.array(scores, np.float32), np.array(wsc, np.float32))
 
 
+def test_parse_lowres_planes_without_a_positive_maximum(nat):
+    """refine's arg-max shortcut takes the plane maximum from the top-k table; a joint whose map is nowhere
+    positive (its top-k rows are padding) or that is zero everywhere (every pixel attains the maximum) must
+    still refine to the oracle's np.argmax.  (Plateaus of equal POSITIVE values are left out: the order in which
+    torch.topk returns tied candidates is not defined, here or in the reference.)"""
+    sets = [synth.make_lowres_maps(P, 192, 256, seed=40 + P) for P in (3, 4)]
+    refined = np.concatenate([s[0] for s in sets]).copy()
+    tags = np.concatenate([s[1] for s in sets])
+    refined[0, 3] = -np.abs(refined[0, 3]) - 0.25          # nowhere positive
+    refined[0, 9] = 0.0                                    # all zero: every pixel attains the maximum
+    refined[1, 11] -= 1.0                                  # nowhere positive, blobs kept
+    refined, tags = torch.from_numpy(refined), torch.from_numpy(tags)
+    res = _parser().parse_lowres(refined.to("cuda:0"), tags.to("cuda:0"), (192, 256))
+    ref = decode_ref.HeatmapParserRef()
+    for n, (people, scores) in enumerate(res):
+        hms = decode_ref.upsample_bilinear(refined[n:n + 1], 192, 256)
+        aes = decode_ref.upsample_bilinear(tags[n:n + 1], 192, 256)
+        want, wsc = ref.parse(hms, aes.unsqueeze(-1))
+        assert len(want[0]) > 0
+        np.testing.assert_array_equal(people, want[0])
+        np.testing.assert_array_equal(np.array(scores, np.float32), np.array(wsc, np.float32))
+
+
 def test_end_to_end_pipeline_and_margin_aware_indices(nat, teacher):
     """forward + decode on the GPU vs oracle forward + oracle decode.  Random-weight
     heat maps are noise, so candidates are compared where the CPU and GPU maps
