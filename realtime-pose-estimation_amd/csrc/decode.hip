@@ -336,7 +336,9 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(Map m, TagMap tm, int t
   const int plane = blockIdx.x;
   const int n = tiles * K;
   u64* gk = cand + (size_t)plane * n;
-  const bool use_lds = (size_t)n * 8 + 32 <= 150 * 1024;
+  constexpr int kOwn = 8;
+  const bool merge_heads = tiles <= kOwn * 256;
+  const bool use_lds = !merge_heads && (size_t)n * 8 + 32 <= 150 * 1024;
   u64* keys = gk;                                         // flat pointer: LDS copy when it fits
   if (use_lds) {
     for (int i = threadIdx.x; i < n; i += 256) lkeys[i] = gk[i];
@@ -345,6 +347,38 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(Map m, TagMap tm, int t
   }
   const int tag_plane = tag_shared_joints > 0 ? plane / tag_shared_joints : plane;
   int found = 0;
+  if (merge_heads) {
+    // every tile list is sorted (largest first, zeros behind): only the heads compete.  A thread keeps the
+    // head of each of its (<= kOwn) tiles in registers and re-reads one key after it won a round
+    u64 head[kOwn];
+    int pos[kOwn];
+#pragma unroll
+    for (int o = 0; o < kOwn; ++o) {
+      const int t = threadIdx.x + o * 256;
+      pos[o] = 0;
+      head[o] = t < tiles ? gk[(size_t)t * K] : 0;
+    }
+    for (int k = 0; k < K; ++k) {
+      u64 mine = head[0];
+#pragma unroll
+      for (int o = 1; o < kOwn; ++o) mine = head[o] > mine ? head[o] : mine;
+      const u64 best = block_max(mine, red);
+      if (best == 0) break;
+#pragma unroll
+      for (int o = 0; o < kOwn; ++o)
+        if (head[o] == best) {                               // keys are unique: exactly one owner
+          ++pos[o];
+          head[o] = pos[o] < K ? gk[(size_t)(threadIdx.x + o * 256) * K + pos[o]] : 0;
+        }
+      if (threadIdx.x == 0) {
+        const unsigned idx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
+        val_k[(size_t)plane * K + k] = unorder_bits((unsigned)(best >> 32));
+        ind_k[(size_t)plane * K + k] = (int)idx;
+      }
+      ++found;
+      __syncthreads();
+    }
+  } else
   for (int k = 0; k < K; ++k) {
     u64 best = 0;
     for (int i = threadIdx.x; i < n; i += 256) best = keys[i] > best ? keys[i] : best;
@@ -360,18 +394,34 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(Map m, TagMap tm, int t
     ++found;
     __syncthreads();
   }
-  // zero padding (single thread; K - found is almost always tiny work)
-  if (threadIdx.x == 0 && found < K) {
-    int k = found;
-    for (int idx = 0; idx < h * w && k < K; ++idx) {
-      const float v = nms_value_at(m, plane, h, w, pad, idx / w, idx - (idx / w) * w);
-      if (v == 0.f) {
+  // zero padding: the first K - found pixels, in index order, whose NMS value is zero.  256 pixels per round,
+  // one per thread (a round almost always suffices); each thread's rank among the zero-valued ones comes from
+  // a ballot + the wave totals.  (One thread walking the pixels cost 200 us per batch: 25 bilinear samples per
+  // pixel, one after the other, in every plane with fewer than K positive maxima - most planes.)
+  {
+    int* wtot = reinterpret_cast<int*>(red);               // 4 wave totals (red is free here)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int total_px = h * w;
+    __syncthreads();
+    for (int base = 0; found < K && base < total_px; base += 256) {
+      const int idx = base + threadIdx.x;
+      bool z = false;
+      if (idx < total_px) z = nms_value_at(m, plane, h, w, pad, idx / w, idx - (idx / w) * w) == 0.f;
+      const unsigned long long mask = __ballot(z);
+      if (lane == 0) wtot[wv] = __popcll(mask);
+      __syncthreads();
+      int before = __popcll(mask & ((1ull << lane) - 1ull));
+      int total = 0;
+      for (int i = 0; i < 4; ++i) { before += i < wv ? wtot[i] : 0; total += wtot[i]; }
+      const int k = found + before;
+      if (z && k < K) {
         val_k[(size_t)plane * K + k] = 0.f;
         ind_k[(size_t)plane * K + k] = idx;
-        ++k;
       }
+      found = found + total < K ? found + total : K;
+      __syncthreads();
     }
-    for (; k < K; ++k) { val_k[(size_t)plane * K + k] = 0.f; ind_k[(size_t)plane * K + k] = 0; }
+    for (int k = found + threadIdx.x; k < K; k += 256) { val_k[(size_t)plane * K + k] = 0.f; ind_k[(size_t)plane * K + k] = 0; }
   }
   __syncthreads();
   __threadfence_block();
@@ -864,7 +914,7 @@ static int topk_run(const Map& m, const TagMap& tm, int planes, int tag_shared_j
     hipLaunchKernelGGL((topk_tile_kernel<Map, -1>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
   RTPE_HIP_CHECK(hipGetLastError());
   size_t lds = 32 + (size_t)tiles * K * 8;
-  if (lds > 150 * 1024) lds = 32;
+  if (lds > 150 * 1024 || tiles <= 8 * 256) lds = 32;     // the head merge (tiles <= kOwn * 256) needs no copy of the lists
   auto kern = topk_merge_kernel<Map, TagMap>;
   static bool attr_set = false;
   if (!attr_set) {
