@@ -134,21 +134,24 @@ struct AxisTab {
   float l0[kTW + 2 * kMaxPad], l1[kTW + 2 * kMaxPad];
 };
 
+// returns false (and leaves `raw` unfilled) only when the caller passed `pos_flag` and no source value under
+// the tile is positive
 template <class Map>
-__device__ __forceinline__ void fill_raw(const Map& m, int plane, int h, int w, int y0, int x0, int pad, float* raw,
-                                         AxisTab*, AxisTab*, float*, int) {
+__device__ __forceinline__ bool fill_raw(const Map& m, int plane, int h, int w, int y0, int x0, int pad, float* raw,
+                                         AxisTab*, AxisTab*, float*, int, int* = nullptr) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH * PW; i += 256) {
     const int py = i / PW, px = i - py * PW;
     const int y = y0 - pad + py, x = x0 - pad + px;
     raw[i] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? m.at(plane, y, x) : -INFINITY;
   }
+  return true;
 }
 
 template <>
-__device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int plane, int h, int w, int y0, int x0,
+__device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int plane, int h, int w, int y0, int x0,
                                                       int pad, float* raw, AxisTab* ty, AxisTab* tx, float* stage,
-                                                      int stage_floats) {
+                                                      int stage_floats, int* pos_flag) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH + PW; i += 256) {
     const bool isy = i < PH;
@@ -173,11 +176,18 @@ __device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int 
   const int er = sr1 - sr0 + 1, ec = sc1 - sc0 + 1;
   const bool staged = stage != nullptr && ky0 <= ky1 && kx0 <= kx1 && er > 0 && ec > 0 && er * ec <= stage_floats;
   if (staged) {
+    bool pos = false;
     for (int i = threadIdx.x; i < er * ec; i += 256) {
       const int r = i / ec, c = i - r * ec;
-      stage[i] = b[(sr0 + r) * m.sw + sc0 + c];
+      const float v = b[(sr0 + r) * m.sw + sc0 + c];
+      stage[i] = v;
+      pos |= v > 0.f;
     }
+    if (pos_flag != nullptr && pos) *pos_flag = 1;         // (the caller zeroed it before the axis-table barrier)
     __syncthreads();
+    // every sample is a combination of these values with weights >= 0: none positive here means no positive
+    // sample, i.e. no candidate in the tile (the top-k only takes positive local maxima)
+    if (pos_flag != nullptr && *pos_flag == 0) return false;
   }
   for (int i = threadIdx.x; i < PH * PW; i += 256) {
     const int py = i / PW, px = i - py * PW;
@@ -202,14 +212,15 @@ __device__ __forceinline__ void fill_raw<BilinearMap>(const BilinearMap& m, int 
     raw[i] = v;
   }
   if (staged) __syncthreads();                          // `stage` becomes the row-max buffer again
+  return true;
 }
 
 template <class Map>
-__device__ __forceinline__ void nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
-                                         float* raw, float* rowmax, AxisTab* ty, AxisTab* tx) {
+__device__ __forceinline__ bool nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
+                                         float* raw, float* rowmax, AxisTab* ty, AxisTab* tx, int* pos_flag = nullptr) {
   // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
-  fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, (kTH + 2 * kMaxPad) * kTW);
+  if (!fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, (kTH + 2 * kMaxPad) * kTW, pos_flag)) return false;
   __syncthreads();
   for (int i = threadIdx.x; i < PH * kTW; i += 256) {
     const int py = i / kTW, px = i - py * kTW;
@@ -218,6 +229,7 @@ __device__ __forceinline__ void nms_tile(const Map& m, int plane, int h, int w, 
     rowmax[i] = v;
   }
   __syncthreads();
+  return true;
 }
 
 template <class Map>
@@ -255,9 +267,13 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
   const int y0 = ty * kTH, x0 = tx * kTW;
   __shared__ AxisTab taby, tabx;
   __shared__ u64 clist[kMaxCand];
-  __shared__ int ccount;
-  if (threadIdx.x == 0) ccount = 0;
-  nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx);
+  __shared__ int ccount, any_positive;
+  if (threadIdx.x == 0) { ccount = 0; any_positive = 0; }
+  if (!nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx, &any_positive)) {
+    u64* outp0 = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;       // nothing positive under this tile
+    for (int r = threadIdx.x; r < K; r += 256) outp0[r] = 0;
+    return;
+  }
   const int PW = kTW + 2 * pad;
   u64 mine[8];   // this thread's 8 pixels as keys (0 = not a positive local maximum)
 #pragma unroll
