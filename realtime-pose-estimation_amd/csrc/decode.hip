@@ -189,27 +189,40 @@ __device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int 
     // sample, i.e. no candidate in the tile (the top-k only takes positive local maxima)
     if (pos_flag != nullptr && *pos_flag == 0) return false;
   }
-  for (int i = threadIdx.x; i < PH * PW; i += 256) {
-    const int py = i / PW, px = i - py * PW;
-    const int r0 = ty->i0[py], c0 = tx->i0[px];
-    float v = -INFINITY;
-    if (r0 >= 0 && c0 >= 0) {
-      const int r1 = ty->i1[py], c1 = tx->i1[px];
-      const float ly0 = ty->l0[py], ly1 = ty->l1[py], lx0 = tx->l0[px], lx1 = tx->l1[px];
-      float v00, v01, v10, v11;
-      if (staged) {
-        const float* s0 = stage + (r0 - sr0) * ec - sc0;
-        const float* s1 = stage + (r1 - sr0) * ec - sc0;
-        v00 = s0[c0]; v01 = s0[c1]; v10 = s1[c0]; v11 = s1[c1];
-      } else {
-        v00 = b[r0 * m.sw + c0]; v01 = b[r0 * m.sw + c1];
-        v10 = b[r1 * m.sw + c0]; v11 = b[r1 * m.sw + c1];
-      }
-      const float t0 = __builtin_fmaf(v00, lx0, v01 * lx1);
-      const float t1 = __builtin_fmaf(v10, lx0, v11 * lx1);
-      v = __builtin_fmaf(t0, ly0, t1 * ly1);
+  // sample (py, px): the four taps and three multiply-adds of F.interpolate(align_corners=True), in its order
+  auto sample = [&](int r0, int r1, float ly0, float ly1, int c0, int c1, float lx0, float lx1) -> float {
+    if (r0 < 0 || c0 < 0) return -INFINITY;               // outside the image
+    float v00, v01, v10, v11;
+    if (staged) {
+      const float* s0 = stage + (r0 - sr0) * ec - sc0;
+      const float* s1 = stage + (r1 - sr0) * ec - sc0;
+      v00 = s0[c0]; v01 = s0[c1]; v10 = s1[c0]; v11 = s1[c1];
+    } else {
+      v00 = b[r0 * m.sw + c0]; v01 = b[r0 * m.sw + c1];
+      v10 = b[r1 * m.sw + c0]; v11 = b[r1 * m.sw + c1];
     }
-    raw[i] = v;
+    const float t0 = __builtin_fmaf(v00, lx0, v01 * lx1);
+    const float t1 = __builtin_fmaf(v10, lx0, v11 * lx1);
+    return __builtin_fmaf(t0, ly0, t1 * ly1);
+  };
+  // lane = column (its axis entry stays in registers), wave = every 4th row (its axis entry is wave-uniform):
+  // per sample only the four taps and the result touch LDS - with one table look-up per sample and axis the
+  // kernel was bound by the LDS instruction rate.  Columns 64.. of the padded tile go in one extra pass.
+  {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c0 = tx->i0[lane], c1 = tx->i1[lane];
+    const float lx0 = tx->l0[lane], lx1 = tx->l1[lane];
+    for (int py = wv; py < PH; py += 4) {
+      const int r0 = __builtin_amdgcn_readfirstlane(ty->i0[py]), r1 = __builtin_amdgcn_readfirstlane(ty->i1[py]);
+      const float ly0 = ty->l0[py], ly1 = ty->l1[py];
+      raw[py * PW + lane] = sample(r0, r1, ly0, ly1, c0, c1, lx0, lx1);
+    }
+    const int extra = PW - 64;                             // 2 * pad columns
+    for (int i = threadIdx.x; i < PH * extra; i += 256) {
+      const int py = i / extra, px = 64 + i - py * extra;
+      raw[py * PW + px] = sample(ty->i0[py], ty->i1[py], ty->l0[py], ty->l1[py], tx->i0[px], tx->i1[px], tx->l0[px],
+                                 tx->l1[px]);
+    }
   }
   if (staged) __syncthreads();                          // `stage` becomes the row-max buffer again
   return true;
