@@ -290,6 +290,29 @@ def test_forward_small_vs_oracle_and_golden(nat, teacher, golden_dir, variant):
     assert torch.equal(p16.float(), preds) and torch.equal(r16.float(), refined)
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (32, 64), (64, 32), (96, 160)])
+def test_forward_smallest_inputs(nat, teacher, hw):
+    """the smallest legal inputs (H, W multiples of 32): branch maps down to 1x1, quarter-resolution maps too
+    narrow for the fused BasicBlock kernel and for the streaming kernel's tiles (fall-back paths).  Criterion
+    as in the test below: the HIP path is no further from exact arithmetic than the reference's CPU half path,
+    and within a few fp16 steps of it"""
+    m, sd = teacher("W1")
+    x = synth.make_images(2, hw[0], hw[1], seed=5)
+    sd16 = {k: (v.half().float() if (v.dim() == 4 or (k.startswith("final_layers") and k.endswith("bias"))) else v)
+            for k, v in sd.items()}
+    ep, er = hrnet_ref.hrnet_forward(sd16, x.half().float(), half=False)
+    cp, cr = hrnet_ref.hrnet_forward(sd, x, half=True)
+    with torch.no_grad():
+        gp, gr = m(x.to("cuda:0"))
+    for name, e, c, g in (("preds", ep, cp, gp.cpu()), ("refined", er, cr, gr.cpu())):
+        ec, eg = (c - e).abs(), (g - e).abs()
+        step = 2.0 ** (np.floor(np.log2(max(float(c.abs().max()), 0.5))) - 10)
+        print("%dx%d %s: |cpu-exact| max %.3e mean %.3e ; |hip-exact| max %.3e mean %.3e ; |hip-cpu| max %.1f steps"
+              % (hw[0], hw[1], name, ec.max(), ec.mean(), eg.max(), eg.mean(), float((g - c).abs().max()) / step))
+        assert eg.mean() <= 1.25 * ec.mean() + 1e-6 and eg.max() <= 1.5 * ec.max() + 1e-6
+        assert float((g - c).abs().max()) <= 6 * step
+
+
 def test_forward_as_close_to_exact_as_the_cpu_half_path(nat, teacher):
     """|HIP - exact| vs |CPU half wrapper - exact|, exact = the same fp16-rounded
     weights evaluated in fp32 without intermediate fp16 roundings: the HIP path
