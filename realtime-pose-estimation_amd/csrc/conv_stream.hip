@@ -626,7 +626,9 @@ bool conv_stream_supports(const ConvPlan& p) {
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
   RTPE_REQUIRE(conv_stream_supports(p), "streaming conv: unsupported plan");
   RTPE_REQUIRE(a.x_bytes > 0 && a.x_bytes < 0x80000000ull, "streaming conv: input view of %zu bytes", (size_t)a.x_bytes);
-  RTPE_REQUIRE(a.cin % 8 == 0 && (a.in_cs == kCC ? a.in_ld >= a.cin : a.in_ld == kCC),
+  // NHWC (chunk stride 48, row of >= cin channels) or plane-major (row of 48, chunk stride = one plane; the two
+  // coincide for a single 1x1 map)
+  RTPE_REQUIRE(a.cin % 8 == 0 && (a.in_ld >= a.cin ? a.in_cs == kCC : a.in_ld == kCC && a.in_cs >= kCC),
                "streaming conv: cin=%d in_ld=%d chunk stride %lld", a.cin, a.in_ld, a.in_cs);
   RTPE_REQUIRE(t.grid >= 8 && t.grid % 8 == 0 && (t.grid / 8) % p.n_cb == 0, "streaming conv: bad grid %d", t.grid);
   RTPE_REQUIRE((t.n_bufs == 2 || t.n_bufs == 3) && t.buf_bytes % 16 == 0 &&

@@ -313,6 +313,34 @@ def test_forward_smallest_inputs(nat, teacher, hw):
         assert float((g - c).abs().max()) <= 6 * step
 
 
+@pytest.mark.parametrize("hw,n", [((32, 32), 1), ((64, 96), 3), ((160, 96), 5)])
+def test_pipeline_on_small_and_odd_batches(nat, teacher, hw, n):
+    """forward + decode of small images / odd batch sizes: the decode of the GPU's own maps through the oracle
+    must be reproduced bit for bit (partial top-k tiles, maps smaller than one tile, 1x1 branch maps)"""
+    from rtpe.engine import TeacherPipeline
+    m, sd = teacher("W0")
+    x = synth.make_images(n, hw[0], hw[1], seed=31 + n)
+    pipe = TeacherPipeline(m, device="cuda:0")
+    with torch.no_grad():
+        preds, refined = pipe.forward(x.to("cuda:0"))
+    res = pipe(x.to("cuda:0"))
+    assert len(res) == n
+    for i in range(n):
+        hms = decode_ref.upsample_bilinear(refined[i:i + 1].cpu(), hw[0], hw[1])
+        aes = decode_ref.upsample_bilinear(preds[i:i + 1].cpu()[:, 17:], hw[0], hw[1])
+        want, wsc = decode_ref.HeatmapParserRef().parse(hms, aes.unsqueeze(-1))
+        if max(hw) > 32:
+            np.testing.assert_array_equal(res[i][0], want[0])
+            np.testing.assert_array_equal(np.array(res[i][1], np.float32), np.array(wsc, np.float32))
+        else:
+            # F.interpolate on the CPU takes another code path for maps this small (16x16 -> 32x32) and rounds
+            # some samples one ulp differently; the kernels follow the path the reference's sizes (>= 512) take.
+            # Positions (and with them the grouping) must still agree exactly, values to one ulp.
+            np.testing.assert_array_equal(res[i][0][..., :2], want[0][..., :2])
+            np.testing.assert_allclose(res[i][0][..., 2:], want[0][..., 2:], rtol=3e-7, atol=0)
+            np.testing.assert_allclose(np.array(res[i][1], np.float32), np.array(wsc, np.float32), rtol=3e-7)
+
+
 def test_forward_as_close_to_exact_as_the_cpu_half_path(nat, teacher):
     """|HIP - exact| vs |CPU half wrapper - exact|, exact = the same fp16-rounded
     weights evaluated in fp32 without intermediate fp16 roundings: the HIP path
