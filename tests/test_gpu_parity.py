@@ -826,6 +826,40 @@ def test_student_other_widths_vs_oracle(nat, inplanes, half):
     assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
 
 
+@pytest.mark.parametrize("hw,n", [((32, 32), 1), ((64, 32), 3), ((96, 224), 2)])
+def test_student_smallest_inputs_vs_oracle(nat, hw, n):
+    """the student (config 5 width) on the smallest legal inputs: 8x8 ... 1x1 maps through the dilated convs,
+    the SE gates and the pooling of the ContextAwareModules"""
+    from oracle import student_ref
+    from rtpe.students import AttentionStudent
+    stu = AttentionStudent(None, "cpu", 100, 17, 1, True, None, False).eval()
+    shapes = {k: tuple(v.shape) for k, v in stu.state_dict().items()}
+    sd = synth.make_state_dict(shapes, 6, "W1")
+    stu.load_state_dict(sd, strict=True)
+    stu = stu.to("cuda:0")
+    x = synth.make_images(n, hw[0], hw[1], seed=13)
+    oa, od = student_ref.student_forward(sd, x, half_stem=True)
+    with torch.no_grad():
+        att, det = stu(x.to("cuda:0"))
+    ea, ed = (att.cpu() - oa).abs().max().item(), (det.cpu() - od).abs().max().item()
+    print("student %dx%d: att %.3e det %.3e (|det| max %.2f)" % (hw[0], hw[1], ea, ed, od.abs().max().item()))
+    assert att.shape == oa.shape and det.shape == od.shape
+    assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
+
+
+def test_batch_invariance_at_awkward_sizes(nat, teacher):
+    """every image of a batch gives the bits it gives alone (7 images of 96x160, 5 of 224x96): launch shapes,
+    plane-major layout and fused blocks depend on the batch size, results must not"""
+    m, sd = teacher("W1")
+    for n, hw in ((7, (96, 160)), (5, (224, 96))):
+        x = synth.make_images(n, hw[0], hw[1], seed=17).to("cuda:0")
+        with torch.no_grad():
+            p, r = m(x)
+            for i in (0, n // 2, n - 1):
+                p1, r1 = m(x[i:i + 1])
+                assert torch.equal(p1[0], p[i]) and torch.equal(r1[0], r[i]), (n, hw, i)
+
+
 def test_other_constructor_configuration_vs_oracle(nat):
     """the network class is not hard-wired to the w48 checkpoint: fewer modules / blocks (constructor arguments of
     pose_higher_hrnet.py:266-287) compile and run the same way; checked against the functional oracle in fp32"""
