@@ -419,6 +419,33 @@ def test_nms_bit_exact(nat):
     assert torch.equal(got.cpu(), want)
 
 
+def test_top_k_on_a_very_large_map(nat):
+    """more tiles per plane than the head merge keeps in registers (2,209 > 2,048: the list-scan fall-back), a
+    sparse plane (few positive maxima: zero padding in index order) and an all-negative one"""
+    g = torch.Generator().manual_seed(5)
+    det = torch.randn(1, 17, 1500, 3000, generator=g)[:, :3].contiguous()
+    det[0, 1] = -det[0, 1].abs()
+    det[0, 1, 700:703, 1500:1503] = torch.tensor([[0.1, 0.2, 0.1], [0.2, 0.9, 0.2], [0.1, 0.2, 0.1]])
+    det[0, 1, 10, 2990] = 0.4
+    det[0, 2] = -det[0, 2].abs() - 0.1
+    tag = torch.randn(1, 17, 1500, 3000, 1, generator=g)[:, :3].contiguous()
+    ref = decode_ref.HeatmapParserRef()
+    ref.params.num_joints = 3
+    par = _parser()
+    par.params.num_joints = 3
+    want = ref.top_k(det, tag)
+    got = par.top_k(det.to("cuda:0"), tag.to("cuda:0"))
+    np.testing.assert_array_equal(got["val_k"], want["val_k"])
+    pos = want["val_k"] > 0                       # among the zero-valued padding ATen's order is not defined
+    assert pos[0, 0].all() and pos[0, 1].sum() == 2 and not pos[0, 2].any()
+    np.testing.assert_array_equal(got["loc_k"][pos], want["loc_k"][pos])
+    np.testing.assert_array_equal(got["tag_k"][pos], want["tag_k"][pos])
+    # the kernels pad with the first zero-valued pixels in index order
+    x, y = got["loc_k"][0, 2, :, 0].astype(np.int64), got["loc_k"][0, 2, :, 1].astype(np.int64)
+    zeros = np.flatnonzero(ref.nms(det[:, 2:3])[0, 0, :2].numpy().reshape(-1) == 0)[:30]
+    assert np.array_equal(y * 3000 + x, zeros)
+
+
 DECODE_CASES = ["p0", "p1", "p3", "p10", "p30", "p3_480", "p5_d2", "p40"]
 
 
