@@ -239,6 +239,24 @@ def test_forward_fp32_vs_oracle_and_golden(nat, w48_shapes, golden_dir):
             assert e1 <= 2e-4                       # fp32 accumulation-order noise only
 
 
+def test_forward_fp32_large_nonsquare_vs_oracle(nat, w48_shapes):
+    """the reference's own test image shape class (1,17,640,960): a large non-square fp32 forward, many units per
+    persistent workgroup, partial tiles on both axes, against the fp32 oracle (seconds on the CPU)"""
+    from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+    sd = synth.make_state_dict(w48_shapes, 0, "W1")
+    net = PoseHigherResolutionNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0").eval()
+    x = synth.make_images(2, 416, 960, seed=21)
+    with torch.no_grad():
+        preds, refined = net(x.to("cuda:0"))
+    assert preds.shape == (2, 34, 104, 240) and refined.shape == (2, 17, 208, 480)
+    op, orf = hrnet_ref.hrnet_forward(sd, x, half=False)
+    e1, e2 = (preds.cpu() - op).abs().max().item(), (refined.cpu() - orf).abs().max().item()
+    print("fp32 416x960: preds %.3e refined %.3e" % (e1, e2))
+    assert e1 <= 2e-4 and e2 <= 2e-4
+
+
 # --------------------------------------------------------------------------- #
 # whole network
 # --------------------------------------------------------------------------- #
