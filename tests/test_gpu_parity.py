@@ -814,6 +814,41 @@ def test_plane_major_inner_tensors_do_not_change_the_network_output(nat, teacher
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
 
 
+def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat, teacher, tmp_path):
+    """two implementations of the same arithmetic: the product configuration (streaming kernel, fused 48-channel
+    blocks, plane-major inner tensors) and a second process that runs every conv on the one-workgroup-per-tile
+    kernel with NHWC tensors must give the SAME bits on a large non-square batch (416x960: partial tiles on both
+    axes, many units per persistent workgroup)"""
+    import subprocess
+    import sys
+    model, sd = teacher("W1")
+    x = synth.make_images(2, 416, 960, seed=23)
+    with torch.no_grad():
+        preds, refined = model(x.to("cuda:0"))
+    out = str(tmp_path / "plain.npz")
+    code = (
+        "import sys, json, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from oracle import synth\n"
+        "from rtpe.helpers import build_hrnet_w48_teacher\n"
+        "shapes = {k: tuple(v) for k, v in json.load(open(%r))['shapes'].items()}\n"
+        "sd = synth.make_state_dict(shapes, 0, 'W1')\n"
+        "m = build_hrnet_w48_teacher({'1.' + k: v for k, v in sd.items()}).to('cuda:0')\n"
+        "x = synth.make_images(2, 416, 960, seed=23)\n"
+        "with torch.no_grad():\n"
+        "    p, r = m(x.to('cuda:0'))\n"
+        "eng = next(iter(m[1]._engines.values()))\n"
+        "kinds = set(eng.op_tile(i, 2, 416, 960)[7] <= -100000 for i in range(len(eng.program.ops)))\n"
+        "assert kinds == {False}, 'a streaming launch shape in the plain configuration'\n"
+        "np.savez(%r, p=p.cpu().numpy(), r=r.cpu().numpy())\n"
+    ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
+         os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
+    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
+    ref = np.load(out)
+    assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
+
+
 def test_eval_student_with_the_dual_head_student(nat, golden_dir):
     """config 5 end to end: AttentionStudent -> (att, det) -> eval_student decodes det (17 heat maps + one shared
     tag map) like validate_hhrnet.py:93-101; keypoints must equal the oracle's decode of the same det maps"""
