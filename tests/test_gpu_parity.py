@@ -359,6 +359,25 @@ def test_pipeline_on_small_and_odd_batches(nat, teacher, hw, n):
             np.testing.assert_allclose(np.array(res[i][1], np.float32), np.array(wsc, np.float32), rtol=3e-7)
 
 
+def test_pipelined_stream_equals_batch_by_batch(nat, teacher):
+    """TeacherPipeline.stream keeps three batches in flight on one stream (forward of batch k, refine of k-1,
+    top-k of k) with tables in recycled pinned buffers: five DIFFERENT batches must decode exactly as they do one
+    at a time, in order"""
+    from rtpe.engine import TeacherPipeline
+    m, sd = teacher("W0")
+    pipe = TeacherPipeline(m, device="cuda:0")
+    batches = [synth.make_images(3, 128, 160, seed=50 + k).to("cuda:0") for k in range(5)]
+    want = [pipe(b) for b in batches]
+    got = list(pipe.stream(iter(batches)))
+    assert len(got) == len(want)
+    for k in range(len(want)):
+        assert len(got[k]) == len(want[k]) == 3
+        for (gp, gs), (wp, ws) in zip(got[k], want[k]):
+            np.testing.assert_array_equal(gp, wp)
+            np.testing.assert_array_equal(np.array(gs, np.float32), np.array(ws, np.float32))
+    assert sum(len(p) for r in want for p, _ in r) > 0
+
+
 def test_forward_as_close_to_exact_as_the_cpu_half_path(nat, teacher):
     """|HIP - exact| vs |CPU half wrapper - exact|, exact = the same fp16-rounded
     weights evaluated in fp32 without intermediate fp16 roundings: the HIP path
