@@ -26,6 +26,11 @@
 //     H: mid-stage, E: before the epilogue reuses the tile buffer);
 //   * MFMA waves: k-loop fully unrolled per half stage, A (weights) and B (pixels)
 //     fragments both read from LDS one k-step ahead of the MFMAs that use them.
+//   * input, output and residual may each be NHWC or plane-major ([C/48][N][H][W][48]: ConvArgs::in_cs /
+//     out_cs / res_cs = element offset of a 48-channel chunk); the engine keeps the inner tensors of a
+//     BasicBlock chain plane-major so that a chunk row is contiguous in memory;
+//   * the epilogue transposes through LDS, adds the residual rows (requested one unit ahead into the fixed
+//     register window v[224:255]) and stores whole 16-byte row pieces from a scalar base + lane offset.
 #include <type_traits>
 
 #include "rtpe_common.h"
