@@ -71,7 +71,6 @@ struct BlockArgs {
   int tiles_x, tiles_y;
   FastDiv div_tiles_x, div_tiles_xy;
   int x_bytes;
-  int stagger;              // diagnostic (RTPE_BLOCK_STAGGER): every other workgroup starts this many kilocycles late
 };
 
 __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const BlockArgs a) {
@@ -241,8 +240,6 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
     xoff[it] = ((oy + 2) * kXW + ox + 2) * kPS + slot * 16;
     epos[it] = ((exists ? oy : 0x7fff) << 16) | (ox << 8) | (slot * 16);
   }
-  if (a.stagger && (jw & 1))
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   int wsel = 0;                                          // ring slot of the next half stage (q % 3)
   for (int u = 0; u < U; ++u) {
     uint32_t n;
@@ -436,8 +433,6 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   a.div_tiles_x = make_fastdiv(a.tiles_x);
   a.div_tiles_xy = make_fastdiv(a.tiles_x * a.tiles_y);
   a.x_bytes = (int)x_bytes;
-  static const int stagger = getenv("RTPE_BLOCK_STAGGER") ? atoi(getenv("RTPE_BLOCK_STAGGER")) : 0;
-  a.stagger = stagger;
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
   long G = 32;                                            // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
