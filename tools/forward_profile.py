@@ -54,16 +54,34 @@ def main():
             tag = " [m%d n%d w%d %dx%d cc%d cb%d%s]" % (tuple(t[:7]) + (kind,))
         key = "%s @/%d%s" % (nm, 1 << ds, tag)
         c = eng.op_cost(i, B, S, S)
+        if t[0] and t[7] == -900002:                      # second conv of a fused BasicBlock: its work belongs to the
+            d = by[head_key]                              # launch of the first (time 0 here)
+            d[1] += acc[i]
+            d[2] += c[0]
+            d[3] += c[1]
+            continue
+        if t[0] and t[7] == -900001:
+            key = key.replace("conv 48->48 k3s1+relu", "block 48->48 (2 convs)")
+            head_key = key
         d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += acc[i]
         d[2] += c[0]
         d[3] += c[1]
     lines = ["# forward only, batch %d, %dx%d, per-op HIP events averaged over %d passes" % (B, S, S, reps),
-             "%-68s %3s %9s %9s %9s %8s" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op")]
+             "# roof = max(FLOPs / 2.5 PFLOP/s, layer-fused bytes / 8 TB/s) / time; a fused BasicBlock is one row (both convs)",
+             "%-68s %3s %9s %9s %9s %8s %6s" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op", "roof")]
     for k, d in sorted(by.items(), key=lambda kv: -kv[1][1]):
-        lines.append("%-68s %3d %9.3f %9.1f %9.1f %8.1f" % (k, d[0], d[1], d[2] / d[1] / 1e9, d[3] / d[1] / 1e6,
-                                                         d[1] / d[0] * 1e3))
+        if d[1] > 0:
+            roof = max(d[2] / 2.5e15, d[3] / 8e12) / (d[1] * 1e-3)
+            lines.append("%-68s %3d %9.3f %9.1f %9.1f %8.1f %6.2f" % (k, d[0], d[1], d[2] / d[1] / 1e9, d[3] / d[1] / 1e6,
+                                                                    d[1] / d[0] * 1e3, roof))
+        else:
+            lines.append("%-68s %3d %9.3f %9s %9s %8.1f %6s" % (k, d[0], 0.0, "-", "-", 0.0, "-"))
+    fl, by_ = sum(d[2] for d in by.values()), sum(d[3] for d in by.values())
+    lines.append("whole forward: %.1f GFLOP, %.1f GB layer-fused -> %.1f TFLOP/s, %.2f TB/s; max(FLOP, byte) bound / time = %.2f"
+                 % (fl / 1e9, by_ / 1e9, fl / acc.sum() / 1e9, by_ / acc.sum() / 1e9,
+                    max(fl / 2.5e15, by_ / 8e12) / (acc.sum() * 1e-3)))
     lines.append("forward total (events) %.3f ms; wall %.3f ms = %.1f img/s" % (acc.sum(), wall, B / wall * 1e3))
     txt = "\n".join(lines)
     print(txt)
