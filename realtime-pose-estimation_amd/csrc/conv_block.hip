@@ -280,10 +280,10 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
             acc1[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc1[m][nt], 0, 0, 0);
         if (kk + 1 < kKH) {
 #pragma unroll
-          for (int i = 0; i < kMT + kNT1; ++i) {
+          for (int i = 0; i < (kMT + kNT1 + 3) / 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -353,10 +353,10 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
             acc2[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc2[m][nt], 0, 0, 0);
         if (kk + 1 < kKH) {
 #pragma unroll
-          for (int i = 0; i < kMT + kNT2; ++i) {
+          for (int i = 0; i < (kMT + kNT2 + 3) / 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);

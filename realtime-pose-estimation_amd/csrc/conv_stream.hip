@@ -403,10 +403,10 @@ conv_stream_kernel(const ConvArgs a) {
       // the matrix pipe never waits for a burst of reads to be issued
       if (kk + 1 < kKH) {
 #pragma unroll
-        for (int i = 0; i < MT + NT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);   // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                       // VALU (address)
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
+        for (int i = 0; i < (MT + NT + 3) / 4; ++i) {                              // four reads per MFMA, early in the step
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                       // VALU (address)
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                       // DS read
         }
       }
       __builtin_amdgcn_sched_barrier(0);
