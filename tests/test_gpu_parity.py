@@ -540,6 +540,24 @@ def test_parse_lowres_batch_equals_per_image_oracle(nat):
         np.testing.assert_array_equal(np.array(scores, np.float32), np.array(wsc, np.float32))
 
 
+@pytest.mark.parametrize("ksize,pad,K,thr", [(3, 1, 10, 0.1), (7, 3, 30, 0.05), (9, 4, 4, 0.2), (1, 0, 30, 0.1)])
+def test_parse_lowres_other_parser_settings(nat, ksize, pad, K, thr):
+    """the parser is not hard-wired to the reference script's settings: other NMS windows (run-time padding path of
+    the tile kernel), people caps and detection thresholds, full pipeline against the oracle"""
+    from rtpe.third_party.group import HeatmapParser
+    refined, tags = synth.make_lowres_maps(6, 224, 320, seed=60 + ksize)
+    refined, tags = torch.from_numpy(refined), torch.from_numpy(tags)
+    par = HeatmapParser(17, K, thr, 1.0, True, False, True, ksize, pad)
+    ref = decode_ref.HeatmapParserRef(17, K, thr, 1.0, True, False, True, ksize, pad)
+    res = par.parse_lowres(refined.to("cuda:0"), tags.to("cuda:0"), (224, 320))
+    hms = decode_ref.upsample_bilinear(refined, 224, 320)
+    aes = decode_ref.upsample_bilinear(tags, 224, 320)
+    want, wsc = ref.parse(hms, aes.unsqueeze(-1))
+    np.testing.assert_array_equal(res[0][0], want[0])
+    np.testing.assert_array_equal(np.array(res[0][1], np.float32), np.array(wsc, np.float32))
+    assert len(want[0]) > 0                        # (grouping may return more people than K: one per unmatched candidate)
+
+
 def test_parse_lowres_planes_without_a_positive_maximum(nat):
     """refine's arg-max shortcut takes the plane maximum from the top-k table; a joint whose map is nowhere
     positive (its top-k rows are padding) or that is zero everywhere (every pixel attains the maximum) must
