@@ -540,7 +540,8 @@ def test_parse_lowres_batch_equals_per_image_oracle(nat):
         np.testing.assert_array_equal(np.array(scores, np.float32), np.array(wsc, np.float32))
 
 
-@pytest.mark.parametrize("ksize,pad,K,thr", [(3, 1, 10, 0.1), (7, 3, 30, 0.05), (9, 4, 4, 0.2), (1, 0, 30, 0.1)])
+@pytest.mark.parametrize("ksize,pad,K,thr", [(3, 1, 10, 0.1), (7, 3, 30, 0.05), (9, 4, 4, 0.2), (1, 0, 30, 0.1),
+                                              (5, 2, 64, 0.1), (5, 2, 1, 0.1)])
 def test_parse_lowres_other_parser_settings(nat, ksize, pad, K, thr):
     """the parser is not hard-wired to the reference script's settings: other NMS windows (run-time padding path of
     the tile kernel), people caps and detection thresholds, full pipeline against the oracle"""
