@@ -230,10 +230,11 @@ __device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int 
 
 template <class Map>
 __device__ __forceinline__ bool nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
-                                         float* raw, float* rowmax, AxisTab* ty, AxisTab* tx, int* pos_flag = nullptr) {
+                                         float* raw, float* rowmax, AxisTab* ty, AxisTab* tx, int* pos_flag = nullptr,
+                                         int rowmax_floats = (kTH + 2 * kMaxPad) * kTW) {
   // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
-  if (!fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, (kTH + 2 * kMaxPad) * kTW, pos_flag)) return false;
+  if (!fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, rowmax_floats, pos_flag)) return false;
   __syncthreads();
   for (int i = threadIdx.x; i < PH * kTW; i += 256) {
     const int py = i / kTW, px = i - py * kTW;
@@ -272,8 +273,9 @@ __global__ void __launch_bounds__(256) nms_kernel(Map m, int h, int w, int pad, 
 template <class Map, int PAD>     // PAD >= 0: the NMS padding as a compile-time constant (divisions by PW become shifts/muls)
 __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad_rt, int K, u64* cand) {
   const int pad = PAD >= 0 ? PAD : pad_rt;
-  __shared__ float raw[(kTH + 2 * kMaxPad) * (kTW + 2 * kMaxPad)];
-  __shared__ float rowmax[(kTH + 2 * kMaxPad) * kTW];
+  constexpr int kP = PAD >= 0 ? PAD : kMaxPad;           // the common 5x5 window needs 19 KiB of tiles, not 21.8: one more block per CU
+  __shared__ float raw[(kTH + 2 * kP) * (kTW + 2 * kP)];
+  __shared__ float rowmax[(kTH + 2 * kP) * kTW];
   __shared__ u64 red[4];
   const int tiles_x = (w + kTW - 1) / kTW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
   __shared__ u64 clist[kMaxCand];
   __shared__ int ccount, any_positive;
   if (threadIdx.x == 0) { ccount = 0; any_positive = 0; }
-  if (!nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx, &any_positive)) {
+  if (!nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx, &any_positive, (kTH + 2 * kP) * kTW)) {
     u64* outp0 = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;       // nothing positive under this tile
     for (int r = threadIdx.x; r < K; r += 256) outp0[r] = 0;
     return;
