@@ -496,7 +496,9 @@ __device__ __forceinline__ float pairwise8_sum(const float* a, int n) {   // num
 
 constexpr int kMaxJ = 32, kMaxD = 32;
 constexpr int kRefineGroup = 16;     // people handled per pass over the pixels
-constexpr int kRefineStripes = 10;   // row stripes per (image, joint) map
+constexpr int kRefineStripes = 10;   // row stripes per (image, joint) map (refine scan)
+constexpr int kArgmaxStripes = 20;   // plane-maximum pass: half the rows per block = half the staged source rows (24 KiB:
+                                     // six blocks per CU instead of three)
 
 // (1) one block per person: copy rows, adjust detected joints (group.py:181-200),
 //     mean tag of the detected joints (group.py:214-222), score (group.py:272)
@@ -894,8 +896,8 @@ static int adjust_refine_run(const Map& m, const TagMap& tm, int n_img, int J, i
     } else {
       RTPE_HIP_CHECK(hipMemsetAsync(plane_key, 0, (size_t)n_img * J * sizeof(u64), s));
     }
-    hipLaunchKernelGGL((plane_argmax_kernel<Map>), dim3(kRefineStripes, n_img * J), dim3(256), 48 * 1024, s, m, h, w,
-                       plane_key, 48 * 1024 / 4, known);
+    hipLaunchKernelGGL((plane_argmax_kernel<Map>), dim3(kArgmaxStripes, n_img * J), dim3(256), 24 * 1024, s, m, h, w,
+                       plane_key, 24 * 1024 / 4, known);
     RTPE_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((refine_shortcut_kernel<TagMap>), dim3((P * J + 255) / 256), dim3(256), 0, s, tm, J, w, D, ans_in,
                        person_img, P, mean_tag, plane_key, best_key, need_scan);
