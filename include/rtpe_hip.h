@@ -248,10 +248,12 @@ int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t W, int32_t 
  * stride in bytes; m_dst_to_src: the 2x3 matrix that maps destination pixel (x, y)
  * to source coordinates (the inverse of what warpAffine is given); dst: (3, oh, ow)
  * fp32.  Bilinear weights in fp32, zero outside the image (documented convention:
- * cv2's fixed-point interpolation is not pinned).  Stream-ordered. */
+ * cv2's fixed-point interpolation is not pinned).  round_u8 != 0: the interpolated
+ * value is rounded to a grey level first (the reference's warp returns a uint8 image);
+ * then x / 255 and (x - mean) / std as torchvision computes them.  Stream-ordered. */
 int rtpe_warp_normalize(const void* src_hwc_u8, int32_t h, int32_t w, int32_t stride_bytes,
                         const float* m_dst_to_src, const float* mean, const float* stdev,
-                        void* dst_chw_f32, int32_t oh, int32_t ow, void* stream);
+                        void* dst_chw_f32, int32_t oh, int32_t ow, int32_t round_u8, void* stream);
 
 /* F.interpolate(mode="bilinear", align_corners=True), fp32 NCHW planes.
  * validate_hhrnet.py:94-98.  src (planes,h,w) -> dst (planes,oh,ow). */

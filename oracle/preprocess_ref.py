@@ -5,7 +5,10 @@ Geometry follows /root/reference/rtpe/third_party/transforms.py: ``get_multi_sca
 uniform scale about the image centre.  The image warp restates the convention of
 csrc/preprocess.hip (fp32 bilinear weights, zero border, pixel centres at integers), NOT
 cv2.warpAffine's fixed-point interpolation: cv2 is not installed, so that part is **parity
-unpinned**  and the expected deviation is about one grey level.
+unpinned**  and the expected deviation is about one grey level.  What follows the warp is
+the published arithmetic of the reference's data flow: the warp returns a uint8 image
+(transforms.py:185-190; ``round_u8``), torchvision's ToTensor divides by 255 and Normalize computes
+``(x - mean) / std`` with a true division (validate_hhrnet.py:63-67).
 """
 import numpy as np
 
@@ -34,7 +37,7 @@ def dst_to_src_matrix(center, scale, size_resized):
     return np.array([[k, 0.0, center[0] - k * dw * 0.5], [0.0, k, center[1] - k * dh * 0.5]])
 
 
-def warp_normalize(img, input_size, mean, std, current_scale=1, min_scale=1):
+def warp_normalize(img, input_size, mean, std, current_scale=1, min_scale=1, round_u8=True):
     """(h, w, 3) uint8 -> (3, H, W) float32, same arithmetic order as the kernel"""
     h, w = img.shape[:2]
     (ow, oh), center, scale = multi_scale_size(h, w, input_size, current_scale, min_scale)
@@ -62,5 +65,7 @@ def warp_normalize(img, input_size, mean, std, current_scale=1, min_scale=1):
             px = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.float32)
             upd = fma(wgt[..., None], px, acc)
             acc = np.where(ok[..., None], upd, acc)
-    out = (acc / f(255.0) - np.asarray(mean, f)) * (f(1.0) / np.asarray(std, f))
+    if round_u8:
+        acc = np.clip(np.floor(acc + f(0.5)), f(0), f(255)).astype(f)
+    out = ((acc / f(255.0) - np.asarray(mean, f)) / np.asarray(std, f)).astype(f)
     return out.transpose(2, 0, 1).astype(f), center, scale

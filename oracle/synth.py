@@ -33,8 +33,15 @@ def make_state_dict(shapes, seed=0, variant="W0", gain=1.0):
     * biases: U(-b, b) with the same b.
     * W0: BatchNorm at identity.  W1: running_mean ~ N(0, .05),
       running_var ~ U(.9, 1.1), weight ~ U(.9, 1.1), bias ~ N(0, .05).
+    * W2: W1, then the heat-map rows of head 0 (``final_layers.0`` outputs [:17], weight and
+      bias) times 1/8 and all of head 1 (``final_layers.1``) times 1/4: the inner activations keep
+      W1's O(1-4) range while the HEAT MAPS span about +-0.7, the span of the real teacher's
+      [0, 1] maps on which BASELINE.json's 1e-3 tolerance is stated; the tag channels keep W1's range.
     """
-    assert variant in ("W0", "W1")
+    assert variant in ("W0", "W1", "W2")
+    head_scale = variant == "W2"
+    if head_scale:
+        variant = "W1"
     sd = {}
     fan_in = {}
     for k, shp in shapes.items():
@@ -68,7 +75,16 @@ def make_state_dict(shapes, seed=0, variant="W0", gain=1.0):
             sd[k] = torch.zeros(shp) if variant == "W0" else torch.randn(shp, generator=g) * 0.05
         else:
             raise KeyError(k)
+    if head_scale:
+        for k in ("final_layers.0.weight", "final_layers.0.bias"):
+            sd[k] = sd[k].clone()
+            sd[k][:W2_HEATMAP_ROWS] *= W2_HEAD0_SCALE
+        for k in ("final_layers.1.weight", "final_layers.1.bias"):
+            sd[k] = sd[k] * W2_HEAD1_SCALE
     return sd
+
+
+W2_HEATMAP_ROWS, W2_HEAD0_SCALE, W2_HEAD1_SCALE = 17, 0.125, 0.25
 
 
 def make_images(n, h=640, w=640, seed=1234):

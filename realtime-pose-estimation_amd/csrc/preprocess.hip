@@ -7,8 +7,11 @@
 // Sampling convention (cv2 is not available to pin its INTER_LINEAR fixed-point scheme, so this
 // is the documented convention of THIS implementation): destination pixel (x, y) samples the
 // source at  M_inv * (x, y, 1)  (pixel centres at integer coordinates, as warpAffine),
-// bilinear weights in fp32 (cv2 quantises them to 1/32 and rounds the result to uint8),
-// out-of-image taps contribute 0 (BORDER_CONSTANT).  HBM-bound: 3 B in, 12 B out per pixel.
+// bilinear weights in fp32 (cv2 quantises them to 1/32), out-of-image taps contribute 0
+// (BORDER_CONSTANT).  With round_u8 the interpolated value is rounded to a grey level
+// (floor(v + 0.5), clamped to [0, 255]) before ToTensor, because the reference's warp returns a
+// uint8 image (transforms.py:185-190); ToTensor and Normalize are the true divisions torchvision
+// performs (x / 255, then (x - mean) / std).  HBM-bound: 3 B in, 12 B out per pixel.
 #include "rtpe_common.h"
 
 namespace rtpe {
@@ -18,7 +21,8 @@ struct WarpArgs {
   float* dst;                 // (3, oh, ow) fp32
   int h, w, stride, oh, ow;
   float m[6];                 // dst -> src:  sx = m0*x + m1*y + m2,  sy = m3*x + m4*y + m5
-  float mean[3], inv_std[3];
+  float mean[3], stdev[3];
+  int round_u8;
 };
 
 __global__ void __launch_bounds__(256) warp_normalize_kernel(const WarpArgs a) {
@@ -44,15 +48,18 @@ __global__ void __launch_bounds__(256) warp_normalize_kernel(const WarpArgs a) {
       }
     }
 #pragma unroll
-  for (int c = 0; c < 3; ++c)     // ToTensor (/255) then Normalize ((t - mean) / std)
-    a.dst[((size_t)c * a.oh + y) * a.ow + x] = (v[c] / 255.f - a.mean[c]) * a.inv_std[c];
+  for (int c = 0; c < 3; ++c) {   // [uint8 image] -> ToTensor (/255) -> Normalize ((t - mean) / std)
+    float g = v[c];
+    if (a.round_u8) g = fminf(fmaxf(floorf(g + 0.5f), 0.f), 255.f);
+    a.dst[((size_t)c * a.oh + y) * a.ow + x] = (g / 255.f - a.mean[c]) / a.stdev[c];
+  }
 }
 
 }  // namespace rtpe
 
 extern "C" int rtpe_warp_normalize(const void* src_hwc_u8, int32_t h, int32_t w, int32_t stride_bytes,
                                    const float* m_dst_to_src, const float* mean, const float* stdev, void* dst_chw_f32,
-                                   int32_t oh, int32_t ow, void* stream) {
+                                   int32_t oh, int32_t ow, int32_t round_u8, void* stream) {
   using namespace rtpe;
   RTPE_REQUIRE(src_hwc_u8 && dst_chw_f32 && m_dst_to_src && mean && stdev, "warp_normalize: null argument");
   RTPE_REQUIRE(h > 0 && w > 0 && oh > 0 && ow > 0 && stride_bytes >= 3 * w, "warp_normalize: h=%d w=%d stride=%d oh=%d ow=%d",
@@ -61,11 +68,12 @@ extern "C" int rtpe_warp_normalize(const void* src_hwc_u8, int32_t h, int32_t w,
   a.src = reinterpret_cast<const unsigned char*>(src_hwc_u8);
   a.dst = reinterpret_cast<float*>(dst_chw_f32);
   a.h = h; a.w = w; a.stride = stride_bytes; a.oh = oh; a.ow = ow;
+  a.round_u8 = round_u8 != 0;
   for (int i = 0; i < 6; ++i) a.m[i] = m_dst_to_src[i];
   for (int c = 0; c < 3; ++c) {
     RTPE_REQUIRE(stdev[c] > 0.f, "warp_normalize: std must be positive");
     a.mean[c] = mean[c];
-    a.inv_std[c] = 1.f / stdev[c];
+    a.stdev[c] = stdev[c];
   }
   hipLaunchKernelGGL(warp_normalize_kernel, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);

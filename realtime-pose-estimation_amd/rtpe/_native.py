@@ -68,7 +68,7 @@ _SIGS = {
     "rtpe_basicblock_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(c_float), POINTER(c_float),
                                        c_void_p, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p]),
     "rtpe_warp_normalize": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),
-                                      POINTER(c_float), c_void_p, c_int32, c_int32, c_void_p]),
+                                      POINTER(c_float), c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "rtpe_bilinear_upsample": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32,
                                          c_int32, c_void_p]),
     "rtpe_nms": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -106,6 +106,38 @@ def test_munkres_cpp_equals_restatement(built):
         assert [tuple(p) for p in py_max_match(c)] == hungarian_ref.munkres_compute(c)
 
 
+def test_munkres_cpp_equals_the_real_munkres_package(built, golden_dir):
+    """the C++ solver (csrc/match_host.cpp) against Munkres().compute of the PyPI package the reference imports
+    (group.py:19-23; vectors made on munkres 1.1.4 by tools/gen_golden.py): 700 mostly tie-heavy matrices"""
+    from rtpe.third_party.group import py_max_match
+    g = np.load(os.path.join(golden_dir, "munkres_vectors.npz"))
+    assert int(g["real_package"]) == 1
+    co = po = n = 0
+    for (nr, nc), npairs in zip(g["shapes"], g["n_pairs"]):
+        c = g["costs"][co:co + nr * nc].reshape(nr, nc)
+        want = g["pairs"][po:po + npairs]
+        got = py_max_match(c.copy())
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, want)
+        co, po, n = co + nr * nc, po + npairs, n + 1
+    assert n >= 500
+
+
+def test_match_by_tag_cpp_equals_the_reference_on_real_munkres(built, golden_dir):
+    """rtpe_match_by_tag against the reference's match_by_tag (group.py:26-97) run on the real package: quantised
+    values / tags (equal-cost optima), people cap, ignore_too_much, use_detection_val off"""
+    from rtpe.third_party.group import Params, match_by_tag
+    g = np.load(os.path.join(golden_dir, "match_vectors.npz"))
+    assert int(g["real_package"]) == 1
+    for i in range(int(g["n_cases"])):
+        mp, udv, itm = [int(v) for v in g["c%d_cfg" % i]]
+        got = match_by_tag((g["c%d_tag" % i], g["c%d_loc" % i].astype(np.int64), g["c%d_val" % i]),
+                           Params(17, mp, 0.1, 1.0, bool(udv), bool(itm)))
+        want = g["c%d_ans" % i]
+        assert got.shape == want.shape, i
+        np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("name", ["p0", "p1", "p3", "p10", "p30", "p3_480", "p5_d2", "p40"])
 def test_match_by_tag_cpp_matches_golden(built, golden_dir, name):
     from rtpe.third_party.group import HeatmapParser, Params, match_by_tag
@@ -298,9 +330,11 @@ def test_stream_kernel_register_window_is_not_allocated(built, tmp_path):
     import re
     import subprocess
     llvm = "/opt/rocm/lib/llvm/bin/"
-    obj = os.path.join(os.path.dirname(built.LIB_PATH), "build", "conv_stream.hip.o")
+    import shutil
+    # a copy: llvm-objcopy without an output file rewrites its input in place, and a test must not touch build products
+    obj = shutil.copy(os.path.join(os.path.dirname(built.LIB_PATH), "build", "conv_stream.hip.o"), str(tmp_path / "s.o"))
     fat, co = str(tmp_path / "s.fatbin"), str(tmp_path / "s.co")
-    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, str(tmp_path / "s2.o")], check=True)
     subprocess.run([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                     "--input=" + fat, "--output=" + co], check=True)
     dis = subprocess.run([llvm + "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout

@@ -14,17 +14,22 @@ What gets pinned:
                       the synthetic blob maps of oracle/synth.py
   bilinear.npz        F.interpolate(bilinear, align_corners=True) sample
 
-``rtpe/third_party/group.py`` imports the PyPI package ``munkres`` which is not
-installed here; following SURVEY.md section 8c a stand-in module is put on
-sys.modules for the import.  Equal-cost assignment ties are common on this
-path (costs are ``round(dist)*100 - val``), and they change the decoded
-people, so the stand-in answers ``Munkres().compute(cost)`` with
-oracle/hungarian_ref.py - a restatement of the package's published procedure
-including its scan orders - and asserts on every call that scipy's optimal
-assignment has the same total cost.  Consequence: decode fixtures pin
-everything in group.py against the reference's own code; which of several
-*equal-cost* optima the real package would pick is pinned only as far as that
-restatement is faithful ("parity unpinned" for ties, DESIGN.md).
+  hrnet_640_w0.npz    640x640 half-wrapper outputs with W0 for images 0 / 17 / 31 of the batch-32 set
+  hrnet_w2.npz        weight set W2 (heat maps of the teacher's span): 128x192 + 640x640
+  two_images.npz      the two bundled data/*.jpg (decoded with PIL) through the body of
+                      validate_hhrnet.py:84-105 on the CPU (W0 and W2)
+  e2e_640.npz         the same loop body on a synthetic 640x640 input (W0 and W2)
+  munkres_vectors.npz Munkres().compute() of the REAL PyPI package on tie-heavy cost matrices
+  match_vectors.npz   match_by_tag (group.py:26-97) on that package, tie-heavy candidate tables
+
+``rtpe/third_party/group.py`` imports the PyPI package ``munkres`` (unpinned, not vendored).  It
+is not installed for this interpreter, but the pure-Python module of munkres 1.1.4 sits in the
+image at /opt/conda/lib/python3.9/site-packages/munkres.py and loads under Python 3.10; it is put on
+sys.modules by path, so every decode fixture comes from the reference's own code running on the
+real package.  Only if that file is missing a stand-in backed by oracle/hungarian_ref.py is used
+(with a loud note; it asserts scipy-optimal total cost on every call).
+
+    python tools/gen_golden.py [--only base,w0_640,w2,two_images,e2e,munkres,match]
 """
 import json
 import os
@@ -41,6 +46,24 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
 
 from oracle import synth  # noqa: E402
+
+
+MUNKRES_PY = "/opt/conda/lib/python3.9/site-packages/munkres.py"
+
+
+def _install_munkres():
+    """the real package by path when the image has it, else the stand-in"""
+    if os.path.exists(MUNKRES_PY):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("munkres", MUNKRES_PY)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        sys.modules["munkres"] = m
+        print("munkres: real package %s from %s" % (getattr(m, "__version__", "?"), MUNKRES_PY))
+        return True
+    print("!!! munkres.py not found: using the oracle/hungarian_ref.py stand-in - tie-breaks are then UNPINNED !!!")
+    _install_munkres_standin()
+    return False
 
 
 def _install_munkres_standin():
@@ -63,16 +86,218 @@ def _install_munkres_standin():
     sys.modules["munkres"] = m
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    _install_munkres_standin()
+HP_KW = dict(max_num_people=30, detection_threshold=0.1, tag_threshold=1.0,
+             use_detection_val=True, ignore_too_much=False, tag_per_joint=True,
+             nms_ksize=5, nms_padding=2)          # validate_hhrnet.py:40-47
+NUM_HEATMAPS = 17
+
+
+class Ref:
+    """the imported reference classes + the teacher factory (body of rtpe/helpers.py:37-72; the module
+    itself needs torchvision)"""
+
+    def __init__(self):
+        sys.path.insert(0, REF)
+        import warnings
+        warnings.simplefilter("ignore")
+        from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+        from rtpe.third_party.fp16_utils.fp16util import network_to_half
+        from rtpe.third_party.group import HeatmapParser
+        self.Net, self.to_half, self.Parser = PoseHigherResolutionNet, network_to_half, HeatmapParser
+        with open(os.path.join(OUT, "w48_shapes.json")) as f:
+            self.shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()} \
+                if os.path.exists(os.path.join(OUT, "w48_shapes.json")) else None
+
+    def teacher(self, sd):
+        m = self.to_half(self.Net())
+        m.load_state_dict({"1." + k: v for k, v in sd.items()}, strict=True)
+        return m.eval()
+
+    def weights(self, variant):
+        return synth.make_state_dict(self.shapes, 0, variant)
+
+
+def _sample(t, stride):
+    return t.numpy()[:, :, ::stride, ::stride].astype(np.float16)     # half-wrapper outputs ARE fp16 values
+
+
+def gen_w0_640(ref):
+    """W0 at the headline size: images 0 / 17 / 31 of the batch-32 set, half wrapper (helpers.py:69-71)"""
+    model = ref.teacher(ref.weights("W0"))
+    x = synth.make_images(32, 640, 640)
+    out = {}
+    for i in (0, 17, 31):
+        with torch.no_grad():
+            ph, rh = model(x[i:i + 1])
+        st = 4 if i == 0 else 8
+        out.update({"img%d_preds_s%d" % (i, st): _sample(ph, st), "img%d_refined_s%d" % (i, st): _sample(rh, st),
+                    "img%d_preds_abs" % i: np.float64(ph.double().abs().sum()),
+                    "img%d_refined_abs" % i: np.float64(rh.double().abs().sum())})
+        print("W0 640 image", i, "range preds %.3f refined %.3f" % (float(ph.abs().max()), float(rh.abs().max())))
+    np.savez_compressed(os.path.join(OUT, "hrnet_640_w0.npz"), **out)
+
+
+def gen_w2(ref):
+    """W2 (oracle/synth.py): inner activations of W1, heat maps of the real teacher's span"""
+    sd = ref.weights("W2")
+    model = ref.teacher(sd)
+    out = {}
+    x = synth.make_images(1, 128, 192)
+    with torch.no_grad():
+        ph, rh = model(x)
+    out["small_preds"], out["small_refined"] = ph.numpy().astype(np.float16), rh.numpy().astype(np.float16)
+    print("W2 128x192 heat maps [%.3f, %.3f] tags [%.3f, %.3f] refined [%.3f, %.3f]" % (
+        float(ph[:, :17].min()), float(ph[:, :17].max()), float(ph[:, 17:].min()), float(ph[:, 17:].max()),
+        float(rh.min()), float(rh.max())))
+    x = synth.make_images(32, 640, 640)
+    for i in (0, 31):
+        with torch.no_grad():
+            ph, rh = model(x[i:i + 1])
+        st = 4 if i == 0 else 8
+        out.update({"img%d_preds_s%d" % (i, st): _sample(ph, st), "img%d_refined_s%d" % (i, st): _sample(rh, st),
+                    "img%d_preds_abs" % i: np.float64(ph.double().abs().sum()),
+                    "img%d_refined_abs" % i: np.float64(rh.double().abs().sum())})
+        print("W2 640 image", i, "heat maps [%.3f, %.3f] tags [%.3f, %.3f] refined [%.3f, %.3f]" % (
+            float(ph[:, :17].min()), float(ph[:, :17].max()), float(ph[:, 17:].min()), float(ph[:, 17:].max()),
+            float(rh.min()), float(rh.max())))
+    np.savez_compressed(os.path.join(OUT, "hrnet_w2.npz"), **out)
+
+
+def _loop_body(ref, model, t, h, w):
+    """validate_hhrnet.py:91-101 on the CPU: forward, two bilinear upsamples to the ORIGINAL (h, w), parse.
+    Also returns top_k's tables of the same maps (group.py:144-179)."""
+    parser = ref.Parser(num_joints=NUM_HEATMAPS, **HP_KW)
+    with torch.no_grad():
+        preds, refined = model(t)
+        hms = torch.nn.functional.interpolate(refined, (h, w), mode="bilinear", align_corners=True)
+        aes = torch.nn.functional.interpolate(preds[:, NUM_HEATMAPS:, :, :], (h, w), mode="bilinear",
+                                              align_corners=True)
+    tk = parser.top_k(hms, aes.unsqueeze(-1))
+    grouped, scores = parser.parse(hms, aes.unsqueeze(-1), adjust=True, refine=True)
+    return preds, refined, tk, grouped[0], np.array(scores, np.float32)
+
+
+def _pack(prefix, preds, refined, tk, final, scores, stride):
+    d = {"preds_s%d" % stride: _sample(preds, stride), "refined_s%d" % stride: _sample(refined, stride),
+         "preds_abs": np.float64(preds.double().abs().sum()), "refined_abs": np.float64(refined.double().abs().sum()),
+         "val_k": tk["val_k"][0], "loc_k": tk["loc_k"][0].astype(np.int32), "tag_k": tk["tag_k"][0],
+         "final": np.asarray(final, np.float32), "scores": scores}
+    return {prefix + k: v for k, v in d.items()}
+
+
+def gen_two_images(ref):
+    """configs[0]: the per-image body of validate_hhrnet.py:84-105 on the two bundled JPEGs.  PIL decodes them
+    (:85); cv2 is not in the image, so the warp of :87 is the numpy restatement of this repo's own convention
+    (oracle/preprocess_ref.py, grey levels rounded to uint8 as cv2.warpAffine returns them); everything after it
+    (:89-101) is the reference's code on the CPU with seeded weights."""
+    from PIL import Image
+    from oracle import preprocess_ref
+    out = {}
+    for name in ("000000001000", "000000002685"):
+        img = np.array(Image.open(os.path.join(REF, "data", name + ".jpg")).convert("RGB"))
+        h, w = img.shape[:2]
+        t, center, scale = preprocess_ref.warp_normalize(img, 640, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+        t = torch.from_numpy(t)[None]
+        out[name + "_img"] = img
+        out[name + "_input_abs"] = np.float64(t.double().abs().sum())
+        out[name + "_center_scale"] = np.concatenate([center, scale]).astype(np.float64)
+        print(name, "image", img.shape, "network input", tuple(t.shape))
+        for variant in ("W0", "W2"):
+            res = _loop_body(ref, ref.teacher(ref.weights(variant)), t, h, w)
+            out.update(_pack("%s_%s_" % (name, variant), *res, stride=8))
+            print("  ", variant, "people", len(res[3]), "candidates > 0.1:", int((res[2]["val_k"] > 0.1).sum()),
+                  "scores", res[4][:3])
+    np.savez_compressed(os.path.join(OUT, "two_images.npz"), **out)
+
+
+def gen_e2e(ref):
+    """the same loop body at the headline size: synthetic 640x640 input (image 0 of the batch-32 set), decode
+    at 640x640"""
+    x = synth.make_images(32, 640, 640)[:1]
+    out = {}
+    for variant in ("W0", "W2"):
+        res = _loop_body(ref, ref.teacher(ref.weights(variant)), x, 640, 640)
+        out.update(_pack(variant + "_", *res, stride=8))
+        print("e2e 640", variant, "people", len(res[3]), "candidates > 0.1:", int((res[2]["val_k"] > 0.1).sum()))
+    np.savez_compressed(os.path.join(OUT, "e2e_640.npz"), **out)
+
+
+def gen_munkres(real):
+    """Munkres().compute of the real package on cost matrices as match_by_tag builds them (group.py:57-80):
+    round(dist)*100 - val with many equal entries, padded to square with 1e10 when there are more candidates than
+    people; plus plain random and constant matrices"""
+    from munkres import Munkres
+    rng = np.random.default_rng(2024)
+    mats, pairs = [], []
+    for i in range(700):
+        a, g = int(rng.integers(1, 31)), int(rng.integers(1, 31))
+        kind = i % 7
+        if kind == 0:
+            c = rng.random((a, g)) * 1000
+        elif kind == 1:
+            c = np.round(rng.random((a, g)) * 3) * 100.0                       # only ties
+        elif kind == 2:
+            c = np.full((a, g), 100.0) - rng.random((a, 1)).astype(np.float32)  # cost depends on the row only
+        else:
+            c = np.round(rng.random((a, g)) * (2 + kind)) * 100 - rng.random((a, 1)).astype(np.float32)
+        if a > g:
+            c = np.concatenate((c, np.zeros((a, a - g)) + 1e10), axis=1)
+        c = np.ascontiguousarray(c, np.float64)
+        res = Munkres().compute(c.tolist() if i % 2 else c.copy())
+        mats.append(c)
+        pairs.append(np.array(res, np.int32).reshape(-1, 2))
+    np.savez_compressed(os.path.join(OUT, "munkres_vectors.npz"),
+                        real_package=np.array(int(real)),
+                        shapes=np.array([m.shape for m in mats], np.int32),
+                        costs=np.concatenate([m.reshape(-1) for m in mats]),
+                        n_pairs=np.array([len(q) for q in pairs], np.int32),
+                        pairs=np.concatenate(pairs))
+    print("munkres vectors:", len(mats), "matrices, real package:", real)
+
+
+def gen_match(real):
+    """match_by_tag (group.py:26-97) of the reference on the real munkres package, on candidate tables built to
+    provoke equal-cost assignments (quantised tags and values), the people cap and dict-key collisions"""
+    sys.path.insert(0, REF)
+    from rtpe.third_party.group import Params, match_by_tag
+    rng = np.random.default_rng(77)
+    J, K = 17, 30
+    out = {"real_package": np.array(int(real))}
+    settings = [dict(), dict(use_detection_val=False), dict(ignore_too_much=True, max_num_people=5),
+                dict(max_num_people=8)]
+    n = 0
+    for trial in range(48):
+        D = int(rng.choice([1, 1, 1, 2]))
+        q = [0.0, 0.05, 0.25][trial % 3]                       # value quantum: 0 = continuous
+        val = rng.random((J, K)).astype(np.float32) * (0.3 if trial % 4 == 0 else 1.0)
+        if q:
+            val = (np.round(val / q) * q).astype(np.float32)
+        val = np.ascontiguousarray(np.sort(val, axis=1)[:, ::-1])
+        loc = rng.integers(0, 640, (J, K, 2)).astype(np.int64)
+        tag = rng.integers(0, 5, (J, K, D)) * (1.5 if trial % 2 else 0.5)
+        if trial % 5:
+            tag = tag + rng.normal(0, 0.2, (J, K, D))
+        tag = tag.astype(np.float32)
+        kw = dict(num_joints=J, max_num_people=30, detection_threshold=0.1, tag_threshold=1.0,
+                  use_detection_val=True, ignore_too_much=False)
+        kw.update(settings[trial % 4])
+        ans = match_by_tag((tag, loc, val), Params(**kw))
+        out["c%d_tag" % n], out["c%d_loc" % n], out["c%d_val" % n] = tag, loc.astype(np.int32), val
+        out["c%d_cfg" % n] = np.array([kw["max_num_people"], int(kw["use_detection_val"]), int(kw["ignore_too_much"])])
+        out["c%d_ans" % n] = np.asarray(ans, np.float32)
+        n += 1
+    out["n_cases"] = np.array(n)
+    np.savez_compressed(os.path.join(OUT, "match_vectors.npz"), **out)
+    print("match vectors:", n, "cases; people per case", [len(out["c%d_ans" % i]) for i in range(0, n, 6)])
+
+
+def gen_base():
     sys.path.insert(0, REF)
     import warnings
     warnings.simplefilter("ignore")
     from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
     from rtpe.third_party.fp16_utils.fp16util import network_to_half
     from rtpe.third_party.group import HeatmapParser
-    torch.set_num_threads(8)
 
     # ---- state-dict contract ------------------------------------------------
     net = PoseHigherResolutionNet().eval()
@@ -170,6 +395,7 @@ def main():
 
 
     # ---- config 5: AttentionStudent(inplanes=100), students.py:595-771 ---------------
+    sys.path.insert(0, REF)
     from rtpe.students import AttentionStudent
     from oracle import student_ref
     torch.manual_seed(0)
@@ -195,6 +421,27 @@ def main():
     print("student bundled weights: oracle vs reference max diff", d_b)
     np.savez_compressed(os.path.join(OUT, "student.npz"), att=att.numpy(), det=det.numpy(),
                         bundled_oracle_vs_reference_maxdiff=np.array(d_b))
+
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="base,w0_640,w2,two_images,e2e,munkres,match")
+    only = set(ap.parse_args().only.split(","))
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    real = _install_munkres()
+    if "base" in only:
+        gen_base()
+    ref = Ref()
+    for name, fn in (("w0_640", gen_w0_640), ("w2", gen_w2), ("two_images", gen_two_images), ("e2e", gen_e2e)):
+        if name in only:
+            fn(ref)
+    if "munkres" in only:
+        gen_munkres(real)
+    if "match" in only:
+        gen_match(real)
 
 
 if __name__ == "__main__":
