@@ -21,6 +21,13 @@
  *     ("host-returning").
  *   - all device work is enqueued on the given stream (stream-ordered,
  *     graph-capturable); handles are independent (one process per GPU).
+ *   - devices: functions that take an rtpe_hrnet handle make the handle's
+ *     device current for the call and restore the caller's device before they
+ *     return (rtpe_hrnet_create included); their buffers and stream must
+ *     belong to that device.  The handle-less launch functions (decode,
+ *     bilinear, warp, single-layer entries) run on HIP's CURRENT device: the
+ *     caller makes the device of the buffers current first (the Python
+ *     binding wraps every call in torch.cuda.device(tensor.device)).
  *   - activations at the boundary are NCHW (what the reference's callers pass
  *     and expect); inside they are NHWC fp16.
  */
@@ -186,6 +193,18 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                         int32_t N, int32_t H, int32_t W,
                         void* preds, void* refined, int32_t out_dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Tuned launch shapes of (N,H,W) as plain integers, so that a caller can keep them across
+ * processes (the reference's cudnn.benchmark has to re-tune in every process).
+ * RTPE_TUNED_INTS int32 per (op, parity class), 4 classes per op:
+ * {pixel tiles/wave (0 = not tuned), waves, tile_h, tile_w, LDS bytes, kind, workgroups,
+ * halo buffer bytes, halo buffers, weight slots}.  rtpe_hrnet_tuned_ints gives the array
+ * length.  Import validates every record against the launch shapes this build offers for
+ * the op at that shape and changes nothing if any record is foreign (RTPE_E_INVALID). */
+#define RTPE_TUNED_INTS 10
+int rtpe_hrnet_tuned_ints(const rtpe_hrnet* h, int32_t* count);
+int rtpe_hrnet_export_tuned(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, int32_t* out, int32_t n);
+int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, const int32_t* in, int32_t n);
 
 /* kernel variant of conv op i for (N,H,W): out8 = {cout tiles/wave, pixel
  * tiles/wave, waves, tile_h, tile_w, channel chunk, cout blocks, v} with

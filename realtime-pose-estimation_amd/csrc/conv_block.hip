@@ -418,11 +418,10 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   RTPE_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= 48 && out_ld >= 48 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
                "basic block: NHWC views must be 16-byte aligned (in_ld=%d out_ld=%d)", in_ld, out_ld);
   RTPE_REQUIRE(x_bytes > 0 && x_bytes < 0x80000000ull, "basic block: input view of %zu bytes", x_bytes);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   BlockArgs a;
   memset(&a, 0, sizeof(a));

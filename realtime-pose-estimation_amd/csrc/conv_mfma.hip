@@ -482,9 +482,9 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
 }
 
 static ConvTile make_stream_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
-  static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
-  static const int force_waves = getenv("RTPE_CONV_WAVES") ? atoi(getenv("RTPE_CONV_WAVES")) : 0;
-  static const int force_th = getenv("RTPE_CONV_TH") ? atoi(getenv("RTPE_CONV_TH")) : 0;
+  static const int force_nt = RTPE_DIAG_ENV_INT("RTPE_CONV_NT", 0);
+  static const int force_waves = RTPE_DIAG_ENV_INT("RTPE_CONV_WAVES", 0);
+  static const int force_th = RTPE_DIAG_ENV_INT("RTPE_CONV_TH", 0);
   double best_score = 1e30;
   ConvTile best;
   memset(&best, 0, sizeof(best));
@@ -514,8 +514,8 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
     if (t.nt) return t;
   }
   static const long lds_cap = getenv("RTPE_CONV_LDS_CAP") ? atol(getenv("RTPE_CONV_LDS_CAP")) : 80 * 1024;
-  static const int force_nt = getenv("RTPE_CONV_NT") ? atoi(getenv("RTPE_CONV_NT")) : 0;
-  static const int force_waves = getenv("RTPE_CONV_WAVES") ? atoi(getenv("RTPE_CONV_WAVES")) : 0;
+  static const int force_nt = RTPE_DIAG_ENV_INT("RTPE_CONV_NT", 0);
+  static const int force_waves = RTPE_DIAG_ENV_INT("RTPE_CONV_WAVES", 0);
   double best_score = 1e30;
   ConvTile best;
   memset(&best, 0, sizeof(best));
@@ -569,21 +569,20 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
-  static const int abl = getenv("RTPE_STREAM_ABL") ? atoi(getenv("RTPE_STREAM_ABL")) : 0;
+  static const int abl = RTPE_DIAG_ENV_INT("RTPE_STREAM_ABL", 0);
   a->ablate = abl;
-  // ablation for profiling only: RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
-  static const int skipk = getenv("RTPE_CONV_SKIPK") ? atoi(getenv("RTPE_CONV_SKIPK")) : 0;
+  // ablations for profiling only (-DRTPE_DIAG builds): RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
+  static const int skipk = RTPE_DIAG_ENV_INT("RTPE_CONV_SKIPK", 0);
   if (skipk) a->kc = 0;
 }
 
 template <typename T, int MT, int NT, int WAVES>
 static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_mask = 0;
   auto kern = conv_mfma_kernel<T, MT, NT, WAVES>;
-  if (!attr_set) {
+  if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y), (unsigned)n_cb);
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), t.lds_bytes, s, a);

@@ -605,12 +605,11 @@ conv_stream_kernel(const ConvArgs a) {
 
 template <int MT, int NT, int WAVES>
 static int launch_stream(const ConvTile& t, const ConvArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_mask = 0;
   auto kern = conv_stream_kernel<MT, NT, WAVES>;
-  if (!attr_set) {
+  if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3((WAVES + kLoaders) * 64), t.lds_bytes, s, a);
   RTPE_HIP_CHECK(hipGetLastError());

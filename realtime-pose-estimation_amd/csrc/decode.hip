@@ -949,11 +949,10 @@ static int topk_run(const Map& m, const TagMap& tm, int planes, int tag_shared_j
   size_t lds = 32 + (size_t)tiles * K * 8;
   if (lds > 150 * 1024 || tiles <= 8 * 256) lds = 32;     // the head merge (tiles <= kOwn * 256) needs no copy of the lists
   auto kern = topk_merge_kernel<Map, TagMap>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(planes), dim3(256), lds, s, m, tm, tag_shared_joints, D, h, w, pad, K, tiles,
                      cand, val_k, ind_k, tag_k);

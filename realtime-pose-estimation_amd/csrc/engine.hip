@@ -74,7 +74,8 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
                                  const void* weights, size_t weights_bytes, int32_t device,
                                  rtpe_hrnet** out) {
   RTPE_REQUIRE(ops && tensors && weights && out && n_ops > 0 && n_tensors > 0, "hrnet_create: null argument");
-  RTPE_HIP_CHECK(hipSetDevice(device));
+  DeviceGuard guard(device);               // the caller's current device is restored on return
+  RTPE_HIP_CHECK(guard.err);
   rtpe_hrnet* h = new rtpe_hrnet();
   h->device = device;
   h->tensors.assign(tensors, tensors + n_tensors);
@@ -233,6 +234,7 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
 
 extern "C" int rtpe_hrnet_destroy(rtpe_hrnet* h) {
   if (!h) return RTPE_OK;
+  DeviceGuard guard(h->device);
   for (auto& kv : h->records)
     for (auto& e : kv.second) hipEventDestroy(e);
   if (h->arena) hipFree(h->arena);
@@ -328,6 +330,10 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
                int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
                std::vector<hipEvent_t>* rec = nullptr) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
+  // kernels, events and function attributes act on HIP's CURRENT device: make the handle's device current for
+  // the call (the stream and every buffer must belong to it) and give the caller's device back afterwards
+  DeviceGuard guard(h->device);
+  RTPE_HIP_CHECK(guard.err);
   RTPE_REQUIRE(N > 0 && H % 32 == 0 && W % 32 == 0 && H >= 32 && W >= 32, "forward: N=%d H=%d W=%d", N, H, W);
   RTPE_REQUIRE(x_dtype == RTPE_DTYPE_F16 || x_dtype == RTPE_DTYPE_F32, "forward: x dtype");
   RTPE_REQUIRE(out_dtype == RTPE_DTYPE_F16 || out_dtype == RTPE_DTYPE_F32, "forward: out dtype");
@@ -866,9 +872,70 @@ extern "C" int rtpe_hrnet_forward_record(rtpe_hrnet* h, const void* x, int32_t x
 
 extern "C" int rtpe_hrnet_read_record(rtpe_hrnet* h, int32_t slot, float* op_ms, int32_t n_ops) {
   RTPE_REQUIRE(h != nullptr && op_ms != nullptr, "read_record: null argument");
+  DeviceGuard guard(h->device);
   auto it = h->records.find(slot);
   RTPE_REQUIRE(it != h->records.end() && it->second.size() == h->ops.size() + 1 && n_ops >= (int)h->ops.size(),
                "read_record: nothing recorded in slot %d", slot);
   RTPE_HIP_CHECK(hipEventSynchronize(it->second.back()));
   return read_op_times(h, it->second, true, op_ms);
+}
+
+// ---- tuned launch shapes: export / import (persisted by the caller, e.g. across processes) -------------------
+// One record of RTPE_TUNED_INTS int32 per (op, parity class): {nt, waves, th, tw, lds_bytes, kind, grid,
+// buf_bytes, n_bufs, n_wslots}; nt == 0 = not tuned.  Import accepts a record only if it is one of the launch
+// shapes conv_enum_tiles offers for that op at this (N, H, W) - a stale or foreign file cannot produce a launch
+// the kernels were not built for - and returns RTPE_E_INVALID without changing anything otherwise.
+extern "C" int rtpe_hrnet_tuned_ints(const rtpe_hrnet* h, int32_t* count) {
+  RTPE_REQUIRE(h != nullptr && count != nullptr, "tuned_ints: null argument");
+  *count = (int32_t)(h->ops.size() * 4 * RTPE_TUNED_INTS);
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_hrnet_export_tuned(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, int32_t* out, int32_t n) {
+  RTPE_REQUIRE(h != nullptr && out != nullptr, "export_tuned: null argument");
+  RTPE_REQUIRE(n >= (int)(h->ops.size() * 4 * RTPE_TUNED_INTS), "export_tuned: buffer too small");
+  auto it = h->tuned.find(std::make_tuple((int)N, (int)H, (int)W));
+  RTPE_REQUIRE(it != h->tuned.end(), "export_tuned: shape %dx%dx%d has not been tuned", N, H, W);
+  for (size_t i = 0; i < it->second.size(); ++i) {
+    const ConvTile& t = it->second[i];
+    int32_t* r = out + i * RTPE_TUNED_INTS;
+    r[0] = t.nt; r[1] = t.waves; r[2] = t.th; r[3] = t.tw; r[4] = (int32_t)t.lds_bytes; r[5] = t.kind;
+    r[6] = t.grid; r[7] = t.buf_bytes; r[8] = t.n_bufs; r[9] = t.n_wslots;
+  }
+  return RTPE_OK;
+}
+
+extern "C" int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, const int32_t* in, int32_t n) {
+  RTPE_REQUIRE(h != nullptr && in != nullptr && N > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
+               "import_tuned: bad argument");
+  const size_t n_ops = h->ops.size();
+  RTPE_REQUIRE(n == (int)(n_ops * 4 * RTPE_TUNED_INTS), "import_tuned: %d values for %zu ops", n, n_ops);
+  std::vector<ConvTile> tiles(n_ops * 4);
+  for (auto& b : tiles) memset(&b, 0, sizeof(b));
+  std::vector<ConvTile> cands;
+  for (size_t i = 0; i < n_ops; ++i) {
+    const OpState& o = h->ops[i];
+    const rtpe_op_desc& d = o.d;
+    for (int k = 0; k < 4; ++k) {
+      const int32_t* r = in + (i * 4 + k) * RTPE_TUNED_INTS;
+      if (r[0] == 0) continue;
+      RTPE_REQUIRE(k < o.n_geom, "import_tuned: op %zu has no launch shape %d", i, k);
+      const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+      const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
+      const bool dc = d.kind == RTPE_OP_DECONV;
+      conv_enum_tiles(o.plan[k], N, dc ? Hi : Hi / d.stride, dc ? Wi : Wi / d.stride, &cands);
+      bool found = false;
+      for (const ConvTile& c : cands) {
+        if (c.nt == r[0] && c.waves == r[1] && c.th == r[2] && c.tw == r[3] && (int32_t)c.lds_bytes == r[4] &&
+            c.kind == r[5] && c.grid == r[6] && c.buf_bytes == r[7] && c.n_bufs == r[8] && c.n_wslots == r[9]) {
+          tiles[i * 4 + k] = c;
+          found = true;
+          break;
+        }
+      }
+      RTPE_REQUIRE(found, "import_tuned: op %zu class %d: not a launch shape of this build", i, k);
+    }
+  }
+  h->tuned[std::make_tuple((int)N, (int)H, (int)W)] = tiles;
+  return RTPE_OK;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -28,6 +29,47 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
       return RTPE_E_INVALID;                    \
     }                                           \
   } while (0)
+
+// Tuning switches (results are bit-identical whatever they are set to: RTPE_CONV_STREAM, RTPE_FUSE_BLOCKS,
+// RTPE_PLANE_MAJOR, RTPE_CONV_LDS_CAP) are read in every build.  DIAGNOSTIC switches - profiling ablations
+// that skip work (wrong results by construction) and forced launch shapes - exist only in a build made with
+// -DRTPE_DIAG (RTPE_BUILD_DEFS=-DRTPE_DIAG): an inherited environment variable cannot corrupt the product.
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#ifdef RTPE_DIAG
+#define RTPE_DIAG_ENV_INT(name, dflt) ::rtpe::env_int(name, dflt)
+#else
+#define RTPE_DIAG_ENV_INT(name, dflt) (dflt)
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
+// launcher runs on the CURRENT device (one mask per kernel template instance)
+inline bool first_use_on_device(unsigned long long* mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  const unsigned long long old = __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
+  return !(old & bit);
+}
+
+// makes `device` current for the lifetime of the object and restores the caller's device
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
 
 // exact unsigned division by a runtime constant: q = umulhi(n, mul) for
 // n * d < 2^32 (all uses here: n < 2^20, d < 2^12)

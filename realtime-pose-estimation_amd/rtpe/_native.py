@@ -53,6 +53,9 @@ _SIGS = {
                                      POINTER(c_double), POINTER(c_double)]),
     "rtpe_hrnet_autotune": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "rtpe_hrnet_tuned_ints": (c_int32, [c_void_p, POINTER(c_int32)]),
+    "rtpe_hrnet_export_tuned": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32), c_int32]),
+    "rtpe_hrnet_import_tuned": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32), c_int32]),
     "rtpe_hrnet_op_tile": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32)]),
     "rtpe_hrnet_plane_major_tensors": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32)]),
     "rtpe_conv2d_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
@@ -140,3 +143,31 @@ def require_gpu(t, what):
 def stream_ptr(device):
     import torch
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(t):
+    """context manager: the device of tensor ``t`` is HIP's current device inside the block.  The handle-less
+    launch functions of the ABI act on the current device (include/rtpe_hip.h, conventions); PyTorch's default
+    stream handle is 0 on every device, so without this a tensor on cuda:1 would be processed by kernels
+    launched on cuda:0."""
+    import torch
+    return torch.cuda.device(t.device)
+
+
+def same_device(what, first, *others):
+    """all tensors of one native call must live on one GPU"""
+    for t in others:
+        if t is not None and t.device != first.device:
+            raise RuntimeError("rtpe: %s: tensors on different devices (%s and %s)" % (what, first.device, t.device))
+
+
+def host_threads(default_cap=16):
+    """host threads this process may use: the cores it is allowed to run on, divided among the ranks of the node
+    (LOCAL_WORLD_SIZE, set by torch.distributed.run) - 8 ranks x 16 matcher threads + 8 torch threads each is
+    exactly the burst that exhausts a container's CPU quota and stalls the kernel launches"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    return max(1, min(default_cap, cores // local_world))

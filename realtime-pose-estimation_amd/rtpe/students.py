@@ -23,7 +23,7 @@ import torch
 
 from . import _native as nat
 from .third_party.fp16_utils.fp16util import network_to_half, tofp16
-from .third_party.pose_higher_hrnet import BN_MOMENTUM, Bottleneck, Engine, ProgramBuilder
+from .third_party.pose_higher_hrnet import BN_MOMENTUM, Bottleneck, CompiledModule, ProgramBuilder
 
 
 def init_weights(module, init_fn=torch.nn.init.kaiming_normal_, bias_val=0.0):
@@ -135,7 +135,7 @@ def get_pretrained_stem(hhrnet_statedict_path, device="cuda", half_precision=Tru
     return stem
 
 
-class AttentionStudent(torch.nn.Module):
+class AttentionStudent(CompiledModule):
     """reference :595-771"""
 
     def __init__(self, hhrnet_statedict_path=None, device="cuda", inplanes=48, num_heatmaps=17, ae_dims=1,
@@ -159,8 +159,7 @@ class AttentionStudent(torch.nn.Module):
             torch.nn.Sequential(torch.nn.Identity(), self.stem)
         if hhrnet_statedict_path is not None:
             self.stem[1].load_pretrained(hhrnet_statedict_path, device, check=False)
-        self._engines = {}
-        self.register_load_state_dict_post_hook(lambda m, k: m._engines.clear())
+        self._init_compiled()
         self.to(device)
         self.device = device
 
@@ -177,11 +176,7 @@ class AttentionStudent(torch.nn.Module):
         """reference :708-722"""
         for name in ("mid_stem", "att_lo", "att_mid", "att_hi", "att_top"):
             getattr(self, name).load_state_dict(torch.load(inpath + name + ".statedict", map_location="cpu"))
-        self._engines.clear()
-
-    def _apply(self, fn, *a, **kw):
-        self._engines.clear()
-        return super()._apply(fn, *a, **kw)
+        self.invalidate()
 
     def compile_program(self):
         """the forward of reference :724-771 as one program"""
@@ -212,11 +207,6 @@ class AttentionStudent(torch.nn.Module):
         """x (N,3,H,W) fp32 on the GPU, H and W multiples of 32 -> (att (N,1,H/4,W/4) = sigmoid mask,
         det (N,num_heatmaps+ae_dims,H/4,W/4)), both fp32.  ``out_hw`` and
         ``return_intermediate`` are accepted and unused, as in the reference."""
-        nat.require_gpu(x, "AttentionStudent.forward")
-        key = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = Engine(self.compile_program(), key)
-            self._engines[key] = eng
-        att, det = eng.forward(x.float(), torch.float32)
+        self._check_inference(x, "AttentionStudent.forward")
+        att, det = self._engine(x.device).forward(x.float(), torch.float32)
         return att, det

@@ -9,13 +9,16 @@ Tolerances (stated here, as BASELINE.json asks):
     <= 2 fp16 steps on every element (steps taken at max(|y|, 0.25): the
     accumulation-order noise is absolute, ~K * 2^-24 * |terms|), > 97 % of the
     elements bit-identical;
-  * whole network, heat maps of O(1) like the real teacher's (weights W0):
-    |heatmap - oracle| <= 1e-3 on EVERY element;
-  * whole network, weights W1 (BatchNorm offsets drive activations to +-4, where
-    ONE fp16 step is 3.9e-3, so 1e-3 is below the storage resolution): <= 4 fp16
-    steps of the output range everywhere, mean error <= 0.5 step.  About 60
-    sequential fp16 roundings compound; the oracle's own fp16-vs-fp32 gap is
-    1e-3...9e-3.
+  * whole network, HEAT MAPS (preds[:, :17] and refined) of the real teacher's span (|x| <= 1):
+    |heatmap - reference| <= 1e-3 on EVERY element - BASELINE.json's tolerance.  Asserted with
+    weights W0 (all activations small) and W2 (inner activations of O(1-4) as with W1, heads scaled
+    so that the heat maps span +-0.7), at 128x192 on every element and at the headline 640x640 against
+    samples of the reference's CPU output (N = 1 and images 0 / 17 / 31 of a batch of 32);
+  * DECLARED DEVIATION: maps whose range exceeds 1 - W1's heat maps
+    (+-4.2) and the TAG channels of W1 / W2 (+-3.2) - live where ONE fp16 step is 2e-3...3.9e-3,
+    so 1e-3 is below the storage resolution of the half wrapper's own outputs: <= 4 fp16 steps of
+    the output range everywhere, mean error <= 0.5 step, and |HIP - exact| no larger than
+    |CPU half wrapper - exact| (test_forward_as_close_to_exact_as_the_cpu_half_path).
 """
 import ctypes
 import os
@@ -274,20 +277,33 @@ def teacher(nat, w48_shapes):
     return make
 
 
-def _check_heatmaps(got, want, name, rng=None):
+HEATMAP_TOL = 1e-3          # BASELINE.json: "heatmap floats within 1e-3"
+
+
+def _check_heatmaps(got, want, name, strict=None):
+    """maps that span <= 1 (the real teacher's heat maps): 1e-3 on every element.  Wider maps (W1's heat maps, the
+    tag channels): the declared deviation of the module docstring.  ``strict`` forces / forbids the 1e-3 branch."""
     got, want = got.astype(np.float64), want.astype(np.float64)
     err = np.abs(got - want)
-    rng = np.abs(want).max() if rng is None else rng
+    rng = max(np.abs(want).max(), np.abs(got).max())
     step = 2.0 ** (np.floor(np.log2(max(rng, 0.5))) - 10)     # one fp16 step at the output range
     print("%s: max|d| %.3e (%.2f steps), mean %.2e, within 1e-3: %.5f, range %.2f"
-          % (name, err.max(), err.max() / step, err.mean(), (err <= 1e-3).mean(), rng))
-    if rng <= 1.0:
-        assert err.max() <= 1e-3, "%s: max error %.3e > 1e-3" % (name, err.max())
+          % (name, err.max(), err.max() / step, err.mean(), (err <= HEATMAP_TOL).mean(), rng))
+    if strict or (strict is None and rng <= 1.0):
+        assert rng <= 1.0, "%s: expected maps of the teacher's span, got range %.2f" % (name, rng)
+        assert err.max() <= HEATMAP_TOL, "%s: max error %.3e > 1e-3" % (name, err.max())
     assert err.max() <= 4 * step, "%s: max error %.3e = %.1f fp16 steps" % (name, err.max(), err.max() / step)
     assert err.mean() <= 0.5 * step, "%s: mean error %.3e" % (name, err.mean())
 
 
-@pytest.mark.parametrize("variant", ["W0", "W1"])
+def _check_outputs(preds, refined, want_preds, want_refined, name, strict):
+    """heat-map channels and tag channels separately (BASELINE.json's tolerance is on the heat maps)"""
+    _check_heatmaps(preds[:, :17], want_preds[:, :17], name + " heat maps (preds[:, :17])", strict)
+    _check_heatmaps(refined, want_refined, name + " refined", strict)
+    _check_heatmaps(preds[:, 17:], want_preds[:, 17:], name + " tags (preds[:, 17:])", None if strict else False)
+
+
+@pytest.mark.parametrize("variant", ["W0", "W1", "W2"])
 def test_forward_small_vs_oracle_and_golden(nat, teacher, golden_dir, variant):
     m, sd = teacher(variant)
     x = synth.make_images(1, 128, 192)
@@ -295,12 +311,16 @@ def test_forward_small_vs_oracle_and_golden(nat, teacher, golden_dir, variant):
         preds, refined = m(x.to("cuda:0"))
     assert preds.dtype == torch.float32 and preds.shape == (1, 34, 32, 48) and refined.shape == (1, 17, 64, 96)
     op, orf = hrnet_ref.hrnet_forward(sd, x, half=True)
-    _check_heatmaps(preds.cpu().numpy(), op.numpy(), variant + " preds vs oracle")
-    _check_heatmaps(refined.cpu().numpy(), orf.numpy(), variant + " refined vs oracle")
-    g = np.load(os.path.join(golden_dir, "hrnet_small.npz"))
-    _check_heatmaps(preds.cpu().numpy(), g[variant + "_half_preds"].astype(np.float32), variant + " preds vs golden")
-    _check_heatmaps(refined.cpu().numpy(), g[variant + "_half_refined"].astype(np.float32),
-                    variant + " refined vs golden")
+    strict = variant != "W1"          # W0 / W2: heat maps of the teacher's span -> 1e-3 on every element
+    _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), op.numpy(), orf.numpy(), variant + " vs oracle", strict)
+    if variant == "W2":
+        g = np.load(os.path.join(golden_dir, "hrnet_w2.npz"))
+        gp, gr = g["small_preds"], g["small_refined"]
+    else:
+        g = np.load(os.path.join(golden_dir, "hrnet_small.npz"))
+        gp, gr = g[variant + "_half_preds"], g[variant + "_half_refined"]
+    _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), gp.astype(np.float32), gr.astype(np.float32),
+                   variant + " vs reference (golden)", strict)
     # the un-fused API surface gives the same bits: tofp16 -> net -> tofp32
     with torch.no_grad():
         p16, r16 = m[1](x.to("cuda:0").half())
@@ -397,18 +417,50 @@ def test_forward_as_close_to_exact_as_the_cpu_half_path(nat, teacher):
         assert eg.mean() <= 1.25 * ec.mean() + 1e-6 and eg.max() <= 1.5 * ec.max() + 1e-6
 
 
-def test_forward_640_vs_golden(nat, teacher, golden_dir):
+def test_forward_640_w1_declared_deviation(nat, teacher, golden_dir):
+    """W1 at 640x640: heat maps of +-4.2 / +-2.8, beyond the span BASELINE.json's 1e-3 is stated on (one fp16 step
+    is 3.9e-3 there).  Asserted: the declared deviation (<= 4 fp16 steps of the range, mean <= 0.5 step); the
+    distribution is printed (DESIGN.md section 2 records it)."""
     m, sd = teacher("W1")
     x = synth.make_images(1, 640, 640)
     with torch.no_grad():
         preds, refined = m(x.to("cuda:0"))
     g = np.load(os.path.join(golden_dir, "hrnet_640.npz"))
-    _check_heatmaps(preds.cpu().numpy()[:, :, ::8, ::8], g["preds_s8"].astype(np.float32), "640 preds",
-                    rng=float(preds.abs().max()))
-    _check_heatmaps(refined.cpu().numpy()[:, :, ::8, ::8], g["refined_s8"].astype(np.float32), "640 refined",
-                    rng=float(refined.abs().max()))
+    _check_outputs(preds.cpu().numpy()[:, :, ::8, ::8], refined.cpu().numpy()[:, :, ::8, ::8],
+                   g["preds_s8"].astype(np.float32), g["refined_s8"].astype(np.float32), "W1 640", False)
     assert abs(float(preds.double().abs().sum()) - float(g["preds_abs"])) < 2e-3 * float(g["preds_abs"])
     assert abs(float(refined.double().abs().sum()) - float(g["refined_abs"])) < 2e-3 * float(g["refined_abs"])
+
+
+@pytest.fixture(scope="module")
+def batch32():
+    return synth.make_images(32, 640, 640)
+
+
+def _check_640_samples(g, i, preds, refined, name, strict=True):
+    st = 4 if i == 0 else 8
+    _check_outputs(preds.cpu().numpy()[:, :, ::st, ::st], refined.cpu().numpy()[:, :, ::st, ::st],
+                   g["img%d_preds_s%d" % (i, st)].astype(np.float32), g["img%d_refined_s%d" % (i, st)].astype(np.float32),
+                   "%s image %d" % (name, i), strict)
+    for t, key in ((preds, "img%d_preds_abs" % i), (refined, "img%d_refined_abs" % i)):
+        assert abs(float(t.double().abs().sum()) - float(g[key])) < 1e-3 * float(g[key])
+
+
+@pytest.mark.parametrize("variant,fixture,images", [("W0", "hrnet_640_w0.npz", (0, 17, 31)),
+                                                    ("W2", "hrnet_w2.npz", (0, 31))])
+def test_forward_640_heatmaps_within_1e_3_of_the_reference(nat, teacher, golden_dir, batch32, variant, fixture, images):
+    """BASELINE.json's bar at the headline size: every sampled heat-map element within 1e-3 of the reference's
+    CPU half-wrapper output (helpers.py:69-71), at N = 1 and inside the batch-32 run the benchmark times
+    (every persistent kernel at full load)"""
+    m, sd = teacher(variant)
+    g = np.load(os.path.join(golden_dir, fixture))
+    with torch.no_grad():
+        p1, r1 = m(batch32[:1].to("cuda:0"))
+        _check_640_samples(g, 0, p1, r1, variant + " 640 N=1")
+        pb, rb = m(batch32.to("cuda:0"))
+    assert torch.equal(pb[0], p1[0]) and torch.equal(rb[0], r1[0])          # batching never changes an image
+    for i in images:
+        _check_640_samples(g, i, pb[i:i + 1], rb[i:i + 1], variant + " 640 batch-32")
 
 
 def test_forward_batch_and_nonsquare(nat, teacher):
@@ -420,8 +472,7 @@ def test_forward_batch_and_nonsquare(nat, teacher):
     for i in range(3):                       # batching never changes an image's result
         assert torch.equal(pb[i], singles[i][0][0]) and torch.equal(rb[i], singles[i][1][0])
     op, orf = hrnet_ref.hrnet_forward(sd, x, half=True)
-    _check_heatmaps(pb.cpu().numpy(), op.numpy(), "batch preds")
-    _check_heatmaps(rb.cpu().numpy(), orf.numpy(), "batch refined")
+    _check_outputs(pb.cpu().numpy(), rb.cpu().numpy(), op.numpy(), orf.numpy(), "W1 batch of 3, 96x160", False)
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 100, 96, device="cuda:0"))
 
@@ -612,6 +663,129 @@ def test_end_to_end_pipeline_and_margin_aware_indices(nat, teacher):
             assert tuple(got_tk["loc_k"][0, j, 0]) == tuple(ref_tk["loc_k"][0, j, 0])
             checked += 1
     print("margin-aware arg-max agreement checked on %d joints" % checked)
+
+
+def _window_margin(plane, x, y):
+    """value at (x, y) minus the largest OTHER value of its 5x5 NMS window (-inf padding as MaxPool2d)"""
+    h, w = plane.shape
+    y0, y1, x0, x1 = max(0, y - 2), min(h, y + 3), max(0, x - 2), min(w, x + 3)
+    win = plane[y0:y1, x0:x1].copy()
+    v = win[y - y0, x - x0]
+    win[y - y0, x - x0] = -np.inf
+    return v - win.max()
+
+
+def _compare_loop_body(g, prefix, model, t, h, w, tag_tol):
+    """The loop body of validate_hhrnet.py:91-101 on the GPU against the reference's CPU run of the same body
+    (fixture ``g``: samples of its maps, its top-k tables, its decoded people).
+
+    (1) heat maps: samples within 1e-3 (tags: ``tag_tol``);
+    (2) the fused GPU decode equals the oracle's decode of the GPU's own maps bit for bit;
+    (3) candidates, ALL entries with val > 0.1 (group.py:41), margin-aware: random-weight maps are noise whose
+        ranking flips under differences far below the 1e-3 tolerance, so a candidate is compared when the GPU
+        map itself proves it stable - it beats every other pixel of its NMS window and the list's cut-off by
+        more than 2 x 1e-3.  Every stable candidate of either side must be a candidate of the other, at the
+        same pixel, with value within 1e-3 and tag within tol; candidates whose values are separated from all
+        others by the margin must come in the same order;
+    (4) people count and scores when the two candidate tables are identical (then the grouping sees the same
+        problem up to value noise)."""
+    from rtpe.engine import TeacherPipeline
+    from rtpe.third_party.group import HeatmapParser, upsample_bilinear
+    tol = HEATMAP_TOL
+    pipe = TeacherPipeline(model, device="cuda:0")
+    with torch.no_grad():
+        preds, refined = pipe.forward(t.to("cuda:0"))
+    # (1)
+    _check_heatmaps(refined.cpu().numpy()[:, :, ::8, ::8], g[prefix + "refined_s8"].astype(np.float32), prefix + "refined", True)
+    _check_heatmaps(preds.cpu().numpy()[:, :17, ::8, ::8], g[prefix + "preds_s8"][:, :17].astype(np.float32),
+                    prefix + "heat maps", True)
+    tag_err = np.abs(preds.cpu().numpy()[:, 17:, ::8, ::8] - g[prefix + "preds_s8"][:, 17:].astype(np.float32)).max()
+    assert tag_err <= tag_tol, tag_err
+    # (2)
+    res = pipe(t.to("cuda:0"), out_hw=(h, w))
+    hms_c = decode_ref.upsample_bilinear(refined.cpu(), h, w)
+    aes_c = decode_ref.upsample_bilinear(preds.cpu()[:, 17:], h, w)
+    want, wsc = decode_ref.HeatmapParserRef().parse(hms_c, aes_c.unsqueeze(-1))
+    np.testing.assert_array_equal(res[0][0], want[0])
+    np.testing.assert_array_equal(np.array(res[0][1], np.float32), np.array(wsc, np.float32))
+    # (3) the GPU's own upsampled maps and top-k lists (K = 30 as the scripts use, K = 45 to see the cut-off)
+    hms = upsample_bilinear(refined, (h, w))
+    aes = upsample_bilinear(preds[:, 17:].contiguous(), (h, w))
+    assert torch.equal(hms.cpu(), hms_c)
+    tk = HeatmapParser(17, 30, 0.1, 1.0, True, False).top_k(hms, aes.unsqueeze(-1))
+    tk45 = HeatmapParser(17, 45, 0.1, 1.0, True, False).top_k(hms, aes.unsqueeze(-1))
+    np.testing.assert_array_equal(tk["val_k"], tk45["val_k"][:, :, :30])
+    H = hms_c[0].numpy()
+    rv, rl, rt = g[prefix + "val_k"], g[prefix + "loc_k"], g[prefix + "tag_k"]
+    gv, gl, gt = tk["val_k"][0], tk["loc_k"][0], tk["tag_k"][0]
+    n_ref = n_ref_stable = n_gpu = n_gpu_stable = n_order = 0
+    identical = True
+    for j in range(17):
+        cut_gpu = tk45["val_k"][0, j, 30]                      # best candidate the K = 30 list leaves out
+        gpos = {(int(x), int(y)): i for i, (x, y) in enumerate(gl[j]) if gv[j, i] > 0.1}
+        rpos = {(int(x), int(y)): i for i, (x, y) in enumerate(rl[j]) if rv[j, i] > 0.1}
+        identical &= [k for k, _ in sorted(gpos.items(), key=lambda kv: kv[1])] == \
+                     [k for k, _ in sorted(rpos.items(), key=lambda kv: kv[1])]
+        for (x, y), i in rpos.items():
+            n_ref += 1
+            v = H[j, y, x]
+            assert abs(v - rv[j, i]) <= tol, (j, i, v, rv[j, i])            # the map value at the reference's maximum
+            if _window_margin(H[j], x, y) > 2 * tol and v - 2 * tol > max(cut_gpu, 0.1):
+                n_ref_stable += 1
+                assert (x, y) in gpos, "stable reference candidate missing on the GPU: joint %d rank %d" % (j, i)
+                k = gpos[(x, y)]
+                assert abs(gv[j, k] - rv[j, i]) <= tol and abs(gt[j, k, 0] - rt[j, i, 0]) <= tag_tol
+        for (x, y), k in gpos.items():
+            n_gpu += 1
+            v = gv[j, k]
+            if _window_margin(H[j], x, y) > 2 * tol and v - 2 * tol > max(rv[j, 29], 0.1):
+                n_gpu_stable += 1
+                assert (x, y) in rpos, "stable GPU candidate missing in the reference: joint %d rank %d" % (j, k)
+        # order: reference candidates separated from every other reference value by the margin
+        common = [(i, gpos[pos]) for pos, i in rpos.items() if pos in gpos]
+        sep = [(i, k) for i, k in common
+               if all(abs(rv[j, i] - rv[j, o]) > 2 * tol for o in range(30) if o != i)]
+        for a in range(len(sep)):
+            for b in range(a + 1, len(sep)):
+                assert (sep[a][0] < sep[b][0]) == (sep[a][1] < sep[b][1])
+                n_order += 1
+    print("%s candidates > 0.1: reference %d (%d stable, compared), GPU %d (%d stable, compared), %d order pairs; tables "
+          "identical: %s" % (prefix, n_ref, n_ref_stable, n_gpu, n_gpu_stable, n_order, identical))
+    assert n_ref >= 100 and n_ref_stable >= 0.5 * n_ref and n_gpu_stable >= 0.5 * n_gpu
+    # (4)
+    ref_people, ref_scores = g[prefix + "final"], g[prefix + "scores"]
+    print("%s people: reference %d, GPU %d" % (prefix, len(ref_people), len(res[0][0])))
+    if identical:
+        assert len(res[0][0]) == len(ref_people)
+        np.testing.assert_allclose(np.sort(np.array(res[0][1], np.float32)), np.sort(ref_scores), atol=2 * tol)
+    return identical
+
+
+@pytest.mark.parametrize("variant,tag_tol", [("W0", 1e-3), ("W2", 1.6e-2)])
+def test_end_to_end_640_vs_the_reference_loop_body(nat, teacher, golden_dir, batch32, variant, tag_tol):
+    """forward -> upsample -> parse at the headline 640x640 against the reference's own CPU run (e2e_640.npz)"""
+    m, sd = teacher(variant)
+    g = np.load(os.path.join(golden_dir, "e2e_640.npz"))
+    _compare_loop_body(g, variant + "_", m, batch32[:1], 640, 640, tag_tol)
+
+
+@pytest.mark.parametrize("name,shape", [("000000001000", (640, 896)), ("000000002685", (640, 768))])
+@pytest.mark.parametrize("variant,tag_tol", [("W0", 1e-3), ("W2", 1.6e-2)])
+def test_two_bundled_images_end_to_end(nat, teacher, golden_dir, name, shape, variant, tag_tol):
+    """configs[0]: the two data/*.jpg of the reference (PIL-decoded pixels in the fixture) through warp ->
+    forward -> decode at the ORIGINAL image size, network inputs 640x896 and 640x768"""
+    from oracle import preprocess_ref
+    from rtpe.third_party import transforms
+    g = np.load(os.path.join(golden_dir, "two_images.npz"))
+    img = g[name + "_img"]
+    h, w = img.shape[:2]
+    t, center, scale = transforms.warp_normalize(img, 640, device="cuda:0")
+    assert tuple(t.shape) == (1, 3) + shape
+    want_t, c2, s2 = preprocess_ref.warp_normalize(img, 640, transforms.IMAGENET_MEAN, transforms.IMAGENET_STD)
+    np.testing.assert_array_equal(np.concatenate([center, scale]), g[name + "_center_scale"])
+    np.testing.assert_array_equal(t[0].cpu().numpy(), want_t)       # the input the reference's forward was given
+    m, sd = teacher(variant)
+    _compare_loop_body(g, "%s_%s_" % (name, variant), m, t, h, w, tag_tol)
 
 
 # --------------------------------------------------------------------------- #

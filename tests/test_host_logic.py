@@ -351,3 +351,69 @@ def test_stream_kernel_register_window_is_not_allocated(built, tmp_path):
             assert mine.search(code), "compiler-allocated register in the window: " + code.strip()
             n_window += 1
     assert n_window > 0
+
+
+def test_compiled_engines_follow_the_weights(built, w48_shapes):
+    """the executor holds a snapshot of the weights: in-place updates (load_state_dict on a sub-module,
+    optimizer-style copy_, init_weights) must be noticed, a .to() that changes nothing must keep the engines, and a
+    module that has engines can be pickled / deep-copied (CPU part: the bookkeeping, with a stand-in engine)"""
+    import copy
+    import pickle
+    from rtpe.helpers import build_hrnet_w48_teacher
+    from rtpe.students import AttentionStudent
+    net = build_hrnet_w48_teacher()[1]
+    assert len(net._fingerprint_tensors()["ts"]) == 1810
+    sentinel = object()
+
+    def arm():
+        net.invalidate()
+        net._engines[0] = sentinel
+        net._fingerprint_tensors()
+
+    def seen_within(calls):
+        return any(net._weights_changed() for _ in range(calls))
+    arm()
+    assert not seen_within(8)                                   # nothing changed
+    net.to("cpu").eval()                                        # same placement: engines are kept
+    assert net._engines.get(0) is sentinel
+    with torch.no_grad():
+        net.final_layers[1].bias.copy_(net.final_layers[1].bias + 1)    # one tensor, in place
+    assert seen_within(4)
+    arm()
+    with torch.no_grad():
+        for p in net.parameters():                              # what an optimizer step does
+            p.add_(0.0)
+    assert net._weights_changed()                               # a bulk update: seen by the very next check
+    arm()
+    net.stage2[0].load_state_dict(net.stage2[0].state_dict())  # load_state_dict on a SUB-module
+    assert 0 not in net._engines
+    arm()
+    net.init_weights()
+    assert 0 not in net._engines
+    arm()
+    net.float()                                                 # new dtype: the packed weights are stale
+    assert 0 not in net._engines
+    net.half()
+    # pickling / deep copies drop the native handles instead of failing on them
+    net._engines[0] = sentinel
+    clone = copy.deepcopy(net)
+    assert clone._engines == {} and net._engines[0] is sentinel
+    assert pickle.loads(pickle.dumps(net))._engines == {}
+    net.invalidate()
+    # training mode / autograd are refused (the executor is inference only)
+    stu = AttentionStudent(None, "cpu", 48, 17, 1, True, None, False)
+    assert stu.training
+    with pytest.raises(RuntimeError):
+        stu(torch.zeros(1, 3, 64, 64))
+
+
+def test_host_thread_budget_is_divided_among_local_ranks(built, monkeypatch):
+    """8 ranks x (16 matcher threads + 8 torch threads) is the burst that exhausts a container's CPU quota:
+    the per-process budget is the allowed cores divided by LOCAL_WORLD_SIZE"""
+    cores = len(os.sched_getaffinity(0))
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert built.host_threads(16) == min(16, cores)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert built.host_threads(16) == max(1, min(16, cores // 8))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1000")
+    assert built.host_threads(16) == 1
