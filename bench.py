@@ -40,11 +40,128 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--weights", default="W0", choices=["W0", "W1"])
+    ap.add_argument("--weights", default="W0", choices=["W0", "W1", "W2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--dump-ops", default="", help="write the per-op table to this file")
+    ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL on a GPU, gloo without)")
+    ap.add_argument("--list", default="", help="configs[3]: a file of image names (one per line, e.g. tests/golden/"
+                                               "coco_minival2017_100.txt); a step = one pass over the whole list, "
+                                               "sharded contiguously over the ranks, uneven shards, short last batches, "
+                                               "all-gather of the keypoint records with counts")
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r02_pmc_summary.json"),
+                    help="per-kernel PMC summary written by tools/pmc_summary.py from rocprofv3 --pmc passes of THIS "
+                         "command; roofline.traffic is read from it")
     return ap.parse_args()
+
+
+def cpu_baseline(sd, x, S):
+    """the CPU path on the host cores this process may use - N = 1 and N = 4, fp32 and the half
+    wrapper, forward and decode separately, min and mean of 3 warm runs.  PyTorch-CPU runs the half wrapper's
+    fp16 convolutions ~400x slower than fp32 on hosts without fp16 vector units (~115 s per 640x640 image on the
+    GPU box), so that leg is timed on a 128x128 crop and scaled by area; everything else runs at full size."""
+    from oracle import decode_ref, hrnet_ref
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    print("cpu baseline: oracle on %d threads ..." % cores, file=sys.stderr, flush=True)
+    xc = x[:4].cpu()
+
+    def timed(fn, runs=3):
+        fn()                                                   # warm-up
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t0)
+        return out, min(ts), sum(ts) / len(ts)
+
+    net32 = hrnet_ref.OracleNet(sd, half=False)
+    rows = {}
+    outs = {}
+    for n in (1, 4):
+        outs[n], mn, mean = timed(lambda: net32(xc[:n]))
+        rows["forward_fp32_N%d" % n] = (mn, mean)
+        print("cpu baseline: fp32 forward N=%d %.2f s" % (n, mean), file=sys.stderr, flush=True)
+
+    def decode(n):
+        p, r = outs[n]
+        for i in range(n):
+            hms = decode_ref.upsample_bilinear(r[i:i + 1], S, S)
+            aes = decode_ref.upsample_bilinear(p[i:i + 1, 17:], S, S)
+            decode_ref.HeatmapParserRef().parse(hms, aes.unsqueeze(-1))
+    for n in (1, 4):
+        _, mn, mean = timed(lambda: decode(n))
+        rows["decode_N%d" % n] = (mn, mean)
+        print("cpu baseline: decode N=%d %.2f s" % (n, mean), file=sys.stderr, flush=True)
+    crop = 128
+    net16 = hrnet_ref.OracleNet(sd, half=True)
+    _, mn, mean = timed(lambda: net16(xc[:1, :, :crop, :crop]))
+    scale = (S / float(crop)) ** 2
+    rows["forward_half_N1_scaled"] = (mn * scale, mean * scale)
+    per_img = rows["forward_fp32_N1"][1] + rows["decode_N1"][1]
+    return {"value": round(1.0 / per_img, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/ on %d torch threads, min / mean of 3 warm runs at %dx%d: fp32 forward N=1 %.3f / %.3f s, "
+                      "N=4 %.3f / %.3f s; bilinear + parse N=1 %.3f / %.3f s, N=4 %.3f / %.3f s; half-wrapper forward "
+                      "N=1 ~%.0f / %.0f s (timed on a %dx%d crop, scaled by area; N=4 not run: 4x that).  value = "
+                      "1 / (fp32 forward + decode, N=1 means): the fastest form of the reference's CPU path" % (
+                          cores, S, S, *rows["forward_fp32_N1"], *rows["forward_fp32_N4"], *rows["decode_N1"],
+                          *rows["decode_N4"], *rows["forward_half_N1_scaled"], crop, crop),
+            "seconds": {k: [round(v[0], 4), round(v[1], 4)] for k, v in rows.items()}}
+
+
+def run_list_mode(args, pipe, dev, rank, world):
+    """configs[3]: the image list sharded over the ranks (rtpe.engine.run_sharded_list).  Images are synthetic
+    (one seeded 640x640 input per image id, generated on the device); a step is one pass over the whole list."""
+    import torch.distributed as dist
+    from rtpe import engine
+    names = [ln.strip() for ln in open(args.list) if ln.strip()]
+    S, B = args.size, args.batch
+    gen = torch.Generator(device=dev)
+    people = [0]
+
+    def infer(part):
+        xb = torch.empty((len(part), 3, S, S), device=dev)
+        for i, nm in enumerate(part):
+            gen.manual_seed(engine.image_id_of(nm))
+            xb[i] = torch.randn(3, S, S, generator=gen, device=dev)
+        res = pipe(xb, out_hw=(S, S))
+        people[0] += sum(len(p) if p.ndim == 3 else 0 for p, _ in res)
+        return res
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+    out = None
+    for _ in range(max(1, args.warmup)):
+        out = engine.run_sharded_list(names, infer, B, dev)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = engine.run_sharded_list(names, infer, B, dev)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        shards = [len(engine.shard_indices(len(names), r, world)) for r in range(world)]
+        print(json.dumps({
+            "metric": "images/sec at 640x640 (HRNet-w48 fwd+decode)", "value": round(len(names) * args.steps / dt, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16 (fp32 accumulate, fp32 BatchNorm; fp32 NCHW in/out)", "data": "synthetic",
+            "config": {"workload": "configs[3]: %d image names of %s sharded over %d rank(s) as %s, batches of <= %d, "
+                                   "one seeded synthetic %dx%d input per image id, keypoint records all-gathered with "
+                                   "counts; every id came back exactly once on every rank" % (
+                                       len(names), os.path.basename(args.list), world, shards, B, S, S),
+                       "images_gathered": len(out), "backend": args.backend or ("nccl" if world > 1 else "none")},
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -55,16 +172,19 @@ def main():
     if world != args.gpus and rank == 0:
         print("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     import torch.distributed as dist
+    from rtpe import _native as nat
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend or "nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     # host thread pools: the box gives one GPU a CPU quota (cgroup); hundreds of idle-spinning OpenMP
-    # threads (torch defaults to one per visible core) exhaust it and the kernel launches stall
-    host_threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8, 8))
+    # threads (torch defaults to one per visible core) exhaust it and the kernel launches stall.  The budget
+    # is the allowed cores divided among the ranks of the node (LOCAL_WORLD_SIZE), for torch's pool here and
+    # for the matcher threads in rtpe.third_party.group
+    host_threads = nat.host_threads(8)
     torch.set_num_threads(host_threads)
 
     import __graft_entry__ as entry
@@ -88,9 +208,14 @@ def main():
     eng = model[1]._engine(dev)
 
     B, S = args.batch, args.size
+    if args.list:
+        return run_list_mode(args, pipe, dev, rank, world)
+    # four different synthetic batches, resident in HBM, fed in turn (a replayed single batch would hide
+    # anything that depends on the data, e.g. buffers sized by the number of decoded people)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    x = torch.randn(B, 3, S, S, generator=g, device=dev)
+    xs = [torch.randn(B, 3, S, S, generator=g, device=dev) for _ in range(4)]
+    x = xs[0]
     ids = [rank * B + i for i in range(B)]
     n_ops = len(eng.program.ops)
     op_ms = np.zeros(n_ops)
@@ -106,7 +231,7 @@ def main():
             # per-op events for the first n_slots timed steps only (their markers cost launch gaps)
             return eng.forward_record(xb, k) if record and k < n_slots else eng.forward(xb)
         last = None
-        for res in pipe.stream((x for _ in range(k_steps)), (S, S), on_forward=fwd):
+        for res in pipe.stream((xs[k % len(xs)] for k in range(k_steps)), (S, S), on_forward=fwd):
             people[0] = sum(len(p) if p.ndim == 3 else 0 for p, _ in res)
             last = pipe.gather(ids, res, equal_counts=True)
         return last
@@ -188,14 +313,22 @@ def main():
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured with
     # rocprofv3 on this kernel and committed under profiles/ (bench.py cannot run the profiler on itself)
     traffic = traffic_src = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
+    pmc = None
+    if os.path.exists(args.pmc_json):
         try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("kernel", "").split("<")[0].split(" ")[0] == dom_kernel.split("<")[0].split(" ")[0] and tj.get("batch") == B:
-                traffic, traffic_src = float(tj["hbm_bytes_per_launch"]["mean"]), "profiles/r01_hbm_traffic.json"
-        except (ValueError, KeyError):
+            with open(args.pmc_json) as f:
+                pj = json.load(f)
+            kname = dom_kernel.split("<")[0].split(" ")[0]
+            ent = pj.get("kernels", {}).get(kname)
+            if ent and pj.get("batch") == B and pj.get("size") == S:
+                # all launches of this kernel in the bench run at 160x160 (the roofline class) and 320x320:
+                # the summary keeps the classes apart by grid size
+                cls = ent.get("classes", {}).get("160x160", ent)
+                traffic = float(cls["hbm_bytes_per_launch"])
+                traffic_src = os.path.relpath(args.pmc_json, ROOT)
+                pmc = {k: cls[k] for k in ("mfma_util", "lds_bank_conflict_frac", "valu_mfma_coexec_frac",
+                                           "fetch_bytes", "write_bytes") if k in cls}
+        except (ValueError, KeyError, TypeError):
             pass
     roofline = {
         "kernel": "%s, 3x3 s1 48->48 @160x160, %d launches/forward" % (dom_kernel, dom_launches),
@@ -207,6 +340,7 @@ def main():
         "forward_tflops": round(total_flops / (fwd_ms_events * 1e-3) / 1e12, 1),
         "forward_mfma_frac": round(total_flops / (fwd_ms_events * 1e-3) / 1e12 / MFMA_PEAK_TFS, 4),
         "forward_hbm_gbs": round(total_bytes / (fwd_ms_events * 1e-3) / 1e9, 1),
+        "counters": pmc,
     }
     if args.dump_ops:
         with open(args.dump_ops, "w") as f:
@@ -218,46 +352,10 @@ def main():
                     d["bytes"] / max(d["ms"], 1e-9) / 1e6, d["ms"] / d["n"] * 1e3))
             f.write("forward total (events) %.3f ms; wall %.3f ms\n" % (fwd_ms_events, fwd_s * 1e3))
 
-    # ---- CPU baseline: the oracle (a port of the reference path) on the host cores
+    # ---- CPU baseline: the oracle (a port of the reference path) on the host cores -------------------
     cpu = None
     if not args.no_cpu_baseline:
-        from oracle import decode_ref, hrnet_ref
-        # the GPU box gives one GPU a share of the host: use the cores we are allowed
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = max(1, min(cores, 16))
-        torch.set_num_threads(cores)
-        print("cpu baseline: oracle on %d threads ..." % cores, file=sys.stderr, flush=True)
-        # fp32 weights: the fastest form of the reference's CPU path on any host (PyTorch-CPU fp16
-        # convolutions, which the half wrapper uses, are 50x slower on CPUs without fp16 units)
-        net = hrnet_ref.OracleNet(sd, half=False)
-        xc = x[:max(1, args.cpu_images)].cpu()
-        c0 = time.perf_counter()
-        n_done = 0
-        t_fwd = t_dec = 0.0
-        for i in range(xc.shape[0]):
-            a0 = time.perf_counter()
-            p, r = net(xc[i:i + 1])
-            a1 = time.perf_counter()
-            hms = decode_ref.upsample_bilinear(r, S, S)
-            aes = decode_ref.upsample_bilinear(p[:, 17:], S, S)
-            decode_ref.HeatmapParserRef().parse(hms, aes.unsqueeze(-1))
-            t_fwd += a1 - a0
-            t_dec += time.perf_counter() - a1
-            n_done += 1
-            print("cpu baseline: image %d done at %.1f s" % (n_done, time.perf_counter() - c0), file=sys.stderr,
-                  flush=True)
-            if time.perf_counter() - c0 > 40:
-                break
-        cdt = time.perf_counter() - c0
-        # the half wrapper itself (what get_hrnet_w48_teacher builds), on a 128x128 crop
-        h0 = time.perf_counter()
-        hrnet_ref.OracleNet(sd, half=True)(xc[:1, :, :128, :128])
-        half_s = (time.perf_counter() - h0) * (S / 128.0) ** 2
-        cpu = {"value": round(n_done / cdt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-               "sample": "%d image(s) of the same synthetic batch at %dx%d: oracle/ forward with fp32 weights "
-                         "(%.2f s) + bilinear + parse (%.2f s) per image on %d torch threads; the half-wrapper "
-                         "forward costs ~%.0f s per image on this host (128x128 crop, scaled by area)"
-                         % (n_done, S, S, t_fwd / max(n_done, 1), t_dec / max(n_done, 1), cores, half_s)}
+        cpu = cpu_baseline(sd, x, S)
 
     value = world * B * args.steps / dt
     out = {

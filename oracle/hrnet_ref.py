@@ -44,20 +44,47 @@ def prepare(sd, half):
     return out
 
 
+class _R16(torch.Tensor):
+    """fp32 tensor that holds fp16 values (``half="emulate"``): the result of ``a + b`` is rounded to fp16 like
+    the half wrapper's add; every other op of this file rounds explicitly"""
+
+    @staticmethod
+    def wrap(t):
+        return t.half().float().as_subclass(_R16)
+
+    def __add__(self, other):
+        return _R16.wrap(torch.Tensor.__add__(self.as_subclass(torch.Tensor), other.as_subclass(torch.Tensor)))
+
+
 class _Net:
+    """``half``: False = plain fp32; True = the half wrapper as PyTorch-CPU runs it (native fp16 tensors; WHICH
+    kernels that takes depends on the host CPU: seconds per image with fp16 vector units, minutes without);
+    "emulate" = the same rounding points (after every conv, BatchNorm and add) with fp32 kernels: not bit-equal to
+    True - the fp32 accumulation ORDER inside a convolution differs, exactly as it does between PyTorch-CPU and
+    the MI355X kernels - but statistically the same thing, and fast on any host.  Used to measure how far two
+    faithful implementations of the half wrapper are apart."""
+
     def __init__(self, sd, half):
-        self.sd = prepare(sd, half)
-        self.half = half
+        self.emulate = half == "emulate"
+        self.sd = prepare(sd, bool(half))
+        if self.emulate:
+            self.sd = {k: v.float() for k, v in self.sd.items()}
+        self.half = bool(half)
+
+    def _r(self, t):
+        return _R16.wrap(t) if self.emulate else t
 
     # ---- leaf ops -------------------------------------------------------- #
     def conv(self, x, key, stride=1, pad=0):
-        return F.conv2d(x, self.sd[key + ".weight"], self.sd.get(key + ".bias"),
-                        stride=stride, padding=pad)
+        x = x.as_subclass(torch.Tensor) if self.emulate else x
+        return self._r(F.conv2d(x, self.sd[key + ".weight"], self.sd.get(key + ".bias"),
+                                stride=stride, padding=pad))
 
     def bn(self, x, key):
         s = self.sd
-        return F.batch_norm(x, s[key + ".running_mean"], s[key + ".running_var"],
-                            s[key + ".weight"], s[key + ".bias"], False, 0.1, BN_EPS)
+        x = x.as_subclass(torch.Tensor) if self.emulate else x
+        return self._r(F.batch_norm(x, s[key + ".running_mean"], s[key + ".running_var"],
+                                    s[key + ".weight"], s[key + ".bias"], False, 0.1, BN_EPS))
 
     def has(self, key):
         return (key + ".weight") in self.sd
@@ -147,6 +174,8 @@ class _Net:
         """conv1..layer1 (pose_higher_hrnet.py:638-644; rtpe/students.py:242-255 StemHRNet.forward)"""
         if self.half:
             x = x.half()                                   # tofp16, fp16util.py:50-51
+            if self.emulate:
+                x = x.float()
         x = F.relu(self.bn(self.conv(x, "conv1", 2, 1), "bn1"))
         x = F.relu(self.bn(self.conv(x, "conv2", 2, 1), "bn2"))
         for b in range(self.count("layer1.")):
@@ -174,13 +203,14 @@ class _Net:
                 x = torch.cat((x, y), 1)
             k = w.shape[-1]
             pad, opad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[k]   # _get_deconv_cfg :535-546
-            x = F.conv_transpose2d(x, w, None, stride=2, padding=pad, output_padding=opad)
+            x = self._r(F.conv_transpose2d(x.as_subclass(torch.Tensor) if self.emulate else x, w, None, stride=2,
+                                           padding=pad, output_padding=opad))
             x = F.relu(self.bn(x, dp + "0.1"))
             for b in range(1, self.count(dp)):
                 x = self.basic_block(x, "%s%d.0." % (dp, b))
             y = self.conv(x, "final_layers.%d" % (i + 1), 1, 1 if fw.shape[-1] == 3 else 0)
             outs.append(y)
-        return [o.float() for o in outs]                   # tofp32, fp16util.py:64-68
+        return [o.float().as_subclass(torch.Tensor) for o in outs]   # tofp32, fp16util.py:64-68
 
 
 @torch.no_grad()

@@ -75,7 +75,8 @@ _PIN_RING = {}
 
 def pack_records(image_ids, results, device):
     """fixed-size keypoint records for the all-gather: per image
-    ``[image_index, n_people, scores[30], kpts[30][17][4]]`` as float32.  On a GPU the records go
+    ``[image_index, n_people, scores[30], kpts[30][17][4]]`` as float32 (image ids are exact up to 2^24;
+    COCO's largest is 581,929).  On a GPU the records go
     through a small ring of pinned host buffers and an asynchronous copy, so packing never waits
     for the kernels queued on the stream."""
     device = torch.device(device)
@@ -272,6 +273,48 @@ def shard_indices(n_items, rank, world):
     base, extra = divmod(n_items, world)
     start = rank * base + min(rank, extra)
     return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def image_id_of(name):
+    """COCO image id of a file name such as ``000000576052.jpg`` (the entries of
+    assets/coco_minival2017_100.txt of the reference); the id is what travels in the keypoint records"""
+    import os
+    stem = os.path.splitext(os.path.basename(str(name).strip()))[0]
+    return int(stem)
+
+
+def run_sharded_list(names, infer, batch_size, device):
+    """configs[3]: one image list, one process per GPU.  ``names`` is the WHOLE list, identical on every rank;
+    this rank takes its contiguous block (``shard_indices``: 100 names over 8 ranks -> 13,13,13,13,12,12,12,12),
+    runs it in batches of ``batch_size`` (the last batch of a shard is short, the shards are uneven) through
+    ``infer(list_of_names) -> [(people, scores)] per name``, and the decoded keypoints of ALL ranks are
+    all-gathered as fixed-size records, with a count exchange because the shards differ in length.  No other
+    collective touches the data path.  Returns ``{image_id: (kpts (P,17,4), scores (P))}`` for the whole list
+    on every rank, after checking that every image of the list came back exactly once."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    mine = shard_indices(len(names), rank, world)
+    ids = [image_id_of(names[i]) for i in range(len(names))]
+    if len(set(ids)) != len(ids):
+        raise ValueError("run_sharded_list: duplicate image ids in the list")
+    recs = []
+    for o in range(0, len(mine), batch_size):
+        part = mine[o:o + batch_size]
+        results = infer([names[i] for i in part])
+        if len(results) != len(part):
+            raise RuntimeError("run_sharded_list: infer returned %d results for %d images" % (len(results), len(part)))
+        recs.append(pack_records([ids[i] for i in part], results, device))
+    rec = torch.cat(recs) if recs else torch.zeros((0, RECORD_FLOATS), dtype=torch.float32, device=device)
+    allrec = all_gather_records(rec) if on else rec
+    out = unpack_records(allrec)
+    got = [int(r) for r in allrec[:, 0].cpu().tolist()]
+    if sorted(got) != sorted(ids):
+        missing = sorted(set(ids) - set(got))
+        dup = sorted({g for g in got if got.count(g) > 1})
+        raise RuntimeError("run_sharded_list: gathered %d records for %d images (missing %s, duplicated %s)"
+                           % (len(got), len(ids), missing[:5], dup[:5]))
+    return out
 
 
 def broadcast_state_dict(sd, src=0, device=None):

@@ -417,3 +417,58 @@ def test_host_thread_budget_is_divided_among_local_ranks(built, monkeypatch):
     assert built.host_threads(16) == max(1, min(16, cores // 8))
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "1000")
     assert built.host_threads(16) == 1
+
+
+def _list_worker(rank, world, port, names, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtpe import engine
+    calls = []
+
+    def infer(part):                                           # fake decode: n people that encode the image id
+        calls.append(len(part))
+        out = []
+        for nm in part:
+            i = engine.image_id_of(nm)
+            n = i % 4
+            out.append((np.full((n, 17, 4), float(i % 1000), np.float32) if n else np.array([], np.float32),
+                        [float(i % 7)] * n))
+        return out
+    res = engine.run_sharded_list(names, infer, 5, "cpu")
+    q.put((rank, calls, {k: (v[0].shape, float(v[0][0, 0, 0]) if len(v[0]) else None, v[1].tolist())
+                         for k, v in res.items()}))
+    dist.destroy_process_group()
+
+
+def test_configs3_list_over_eight_ranks_gloo(golden_dir):
+    """configs[3] control path without hardware: the 100 names of coco_minival2017_100.txt sharded over 8
+    ranks (13,13,13,13,12,12,12,12), batches of 5 with short tails, variable-count all-gather, every image exactly
+    once on every rank.  (The decode is faked; the collective code is the one bench.py --list runs on RCCL.)"""
+    import torch.multiprocessing as mp
+    from rtpe import engine
+    names = [ln.strip() for ln in open(os.path.join(golden_dir, "coco_minival2017_100.txt")) if ln.strip()]
+    assert len(names) == 100
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_list_worker, args=(r, 8, port, names, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ids = sorted(engine.image_id_of(n) for n in names)
+    for rank, calls, res in got:
+        assert calls == ([5, 5, 3] if rank < 4 else [5, 5, 2])
+        assert sorted(res) == ids
+        for i, (shape, first, scores) in res.items():
+            assert shape == (i % 4, 17, 4) and scores == [float(i % 7)] * (i % 4)
+            assert first is None or first == float(i % 1000)
+    # single process: the same function without a process group
+    out = engine.run_sharded_list(names[:7], lambda part: [(np.array([], np.float32), []) for _ in part], 3, "cpu")
+    assert len(out) == 7
+    with pytest.raises(ValueError):
+        engine.run_sharded_list(names[:2] + names[:1], lambda part: [(np.array([], np.float32), [])] * len(part), 3, "cpu")
