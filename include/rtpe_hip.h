@@ -194,6 +194,11 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                         void* preds, void* refined, int32_t out_dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Process-wide tuning options; every setting gives bit-identical results (they select between kernel
+ * variants for A/B measurements in one process).  "block_ring" = 1: the fused BasicBlock kernel streams its
+ * weights through a 3-slot LDS ring instead of keeping them resident (default 0; env RTPE_BLOCK_RING). */
+int rtpe_set_option(const char* name, int32_t value);
+
 /* Tuned launch shapes of (N,H,W) as plain integers, so that a caller can keep them across
  * processes (the reference's cudnn.benchmark has to re-tune in every process).
  * RTPE_TUNED_INTS int32 per (op, parity class), 4 classes per op:

@@ -410,6 +410,293 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant with RESIDENT weights (the default): the weight fragments of both convs (4 half-stage sets,
+// 84 KiB) are loaded into LDS once per workgroup instead of streaming through a 3-slot ring for every
+// unit (84 KiB of L2 -> LDS traffic per unit against 34 KiB for the x tile, and two of the five barriers
+// of a unit only handed weight slots over).  LDS then holds ONE x tile; to keep prefetching, each MFMA
+// wave takes its residual row pieces of the tile into registers before conv1, so the tile buffer is
+// free as soon as conv1's last k-step has read it and the next tile streams in underneath conv2 and
+// the output epilogue.  All three loader waves move x rows.  Three barriers per unit:
+//   M  : x tile u (and, for u = 0, the weights) has landed;
+//   A2 : the mid tile is complete - and the x buffer is free: tile u+1 is requested;
+//   E2 : every wave is done reading the mid tile (the output transposition reuses it).
+// Same k order, same rounding points: bit-identical to the ring variant and to the two-launch path.
+// LDS: 84 KiB weights + 33.75 KiB x tile + 25.5 KiB mid tile = 143.25 KiB.
+namespace {
+constexpr int kLdsRW = 4 * kWSlot + kXBytes + kMidBytes;
+}
+
+__global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(const BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wts = smem;                                  // [conv1 half 0][conv1 half 1][conv2 half 0][conv2 half 1]
+  char* const xb = smem + 4 * kWSlot;
+  char* const mid = xb + kXBytes;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int n_tiles = a.N * a.tiles_x * a.tiles_y;
+  const int G = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd;
+  const int tiles_xcd = min(per_xcd, n_tiles - t_begin);
+  const int U = jw < tiles_xcd ? (tiles_xcd - jw + G - 1) / G : 0;
+  if (U == 0) return;
+  const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
+  auto unit_origin = [&](int u, uint32_t* n, int* py0, int* px0) __attribute__((always_inline)) {
+    uint32_t t = (uint32_t)(t_begin + jw + u * G);
+    *n = fdiv(t, a.div_tiles_xy);
+    t -= *n * tiles_xy;
+    const uint32_t tyi = fdiv(t, a.div_tiles_x);
+    *py0 = (int)tyi * kTH;
+    *px0 = (int)(t - tyi * a.tiles_x) * kTW;
+  };
+
+  if (wv >= kWaves) {
+    // ------------------------------- loader waves -------------------------------
+    const int jl = wv - kWaves;                          // rows [0,4), [4,7), [7,10) of every x tile
+    const int r0 = jl == 0 ? 0 : jl == 1 ? 4 : 7, r1 = jl == 0 ? 4 : jl == 1 ? 7 : 10;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, a.x_bytes, 0x00020000);
+    constexpr int rowslots = kXW * 6;
+    auto issue = [&](int u) __attribute__((always_inline)) {
+      uint32_t n;
+      int py0, px0;
+      unit_origin(u, &n, &py0, &px0);
+      const int iy0 = py0 - 2, ix0 = px0 - 2;
+      uint32_t voff[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = k * 64 + lane;
+        const int hx = q / 6, sl = q - hx * 6;
+        const int ix = ix0 + hx;
+        voff[k] = (unsigned)ix < (unsigned)a.W ? (uint32_t)(ix * a.in_ld + sl * 8) * 2u : 0x80000000u;
+      }
+      const int img_row0 = (int)n * a.H;
+      for (int r = r0; r < r1; ++r) {
+        const int iy = iy0 + r;
+        const bool row_ok = (unsigned)iy < (unsigned)a.H;
+        const int soff = row_ok ? (img_row0 + iy) * a.W * a.in_ld * 2 : 0;
+        char* dst = xb + r * (kXW * kPS);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k * 64 + lane < rowslots)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + k * 1024), 16,
+                                                     (int)(row_ok ? voff[k] : 0x80000000u), soff, 0, 0);
+      }
+    };
+    // the weights, once: conv1 by loader 0, conv2 by loader 1 (42 KiB each); loader 2 starts on the tile
+    if (jl < 2) {
+      __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(jl == 0 ? a.w1 : a.w2), 0,
+                                                                    2 * kWSlot, 0x00020000);
+      char* dst = wts + jl * 2 * kWSlot;
+      const int voff = lane * 16;
+      for (int p = 0; p < 2 * kMT * kKH; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + p * 1024), 16, voff, p * 1024, 0, 0);
+    }
+    issue(0);
+    for (int u = 0; u < U; ++u) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this loader's rows of tile u (and weights) have landed
+      RTPE_BBARRIER();                                   // M
+      RTPE_BBARRIER();                                   // A2: conv1 has read the tile, residual pieces are in registers
+      if (u + 1 < U) issue(u + 1);
+      RTPE_BBARRIER();                                   // E2
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // -------------------------------- MFMA waves --------------------------------
+  const int r = lane & 15, g = lane >> 4;
+  int toff1[2 * kKH], toff2[2 * kKH];
+#pragma unroll
+  for (int k = 0; k < 2 * kKH; ++k) {
+    int kk = k * 32 + g * 8;
+    if (kk >= 9 * 48) kk -= 9 * 48;
+    const int tap = kk / 48, c = kk - tap * 48;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    toff1[k] = (ty * kXW + tx) * kPS + c * 2;
+    toff2[k] = (ty * kMW + tx) * kPS + c * 2;
+  }
+  int pix1[kNT1], pix2[kNT2];
+#pragma unroll
+  for (int nt = 0; nt < kNT1; ++nt) {
+    int p = (wv * kNT1 + nt) * 16 + r;
+    p = p < kMH * kMW ? p : kMH * kMW - 1;
+    const int my = p / kMW, mx = p - my * kMW;
+    pix1[nt] = (my * kXW + mx) * kPS;
+  }
+#pragma unroll
+  for (int nt = 0; nt < kNT2; ++nt) {
+    const int p = (wv * kNT2 + nt) * 16 + r;
+    pix2[nt] = ((p >> 5) * kMW + (p & 31)) * kPS;
+  }
+  float4v al1[kMT], be1[kMT], al2[kMT], be2[kMT];
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) {
+    const int c4 = m * 16 + g * 4;
+    al1[m] = *reinterpret_cast<const float4v*>(a.ab1 + c4);
+    be1[m] = *reinterpret_cast<const float4v*>(a.ab1 + 48 + c4);
+    al2[m] = *reinterpret_cast<const float4v*>(a.ab2 + c4);
+    be2[m] = *reinterpret_cast<const float4v*>(a.ab2 + 48 + c4);
+  }
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) asm volatile("" ::"v"(al1[m]), "v"(be1[m]), "v"(al2[m]), "v"(be2[m]));
+
+  int eoff[kNIT], xoff[kNIT], epos[kNIT];
+#pragma unroll
+  for (int it = 0; it < kNIT; ++it) {
+    int c = it * 64 + lane;
+    const bool exists = c < kNT2 * 16 * 6;
+    c = exists ? c : 0;
+    const int pw = c / 6, slot = c - pw * 6;
+    const int p = wv * kNT2 * 16 + pw;
+    const int oy = p >> 5, ox = p & 31;
+    eoff[it] = pw * kRowB + slot * 16;
+    xoff[it] = ((oy + 2) * kXW + ox + 2) * kPS + slot * 16;
+    epos[it] = ((exists ? oy : 0x7fff) << 16) | (ox << 8) | (slot * 16);
+  }
+
+  // one conv: 14 k-steps straight through (no hand-over in the middle: the weights are resident)
+  auto kloop = [&](const char* wbase, const char* tile, const int* pix, const int* toff, auto acc, auto ntc)
+      __attribute__((always_inline)) {
+    constexpr int NT = decltype(ntc)::value;
+    const char* wl = wbase + lane * 16;
+    half8 af[2][kMT], bf[2][NT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const half8*>(tile + pix[nt] + toff[0]);
+#pragma unroll
+    for (int kk = 0; kk < 2 * kKH; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < 2 * kKH) {
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 1) * kMT + m) * 1024);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nxt][nt] = *reinterpret_cast<const half8*>(tile + pix[nt] + toff[kk + 1]);
+      }
+#pragma unroll
+      for (int m = 0; m < kMT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc[m][nt], 0, 0, 0);
+      if (kk + 1 < 2 * kKH) {
+#pragma unroll
+        for (int i = 0; i < (kMT + NT + 3) / 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  for (int u = 0; u < U; ++u) {
+    uint32_t n;
+    int py0, px0;
+    unit_origin(u, &n, &py0, &px0);
+
+    RTPE_BBARRIER();                                     // M: x tile u (and the weights) are in LDS
+    // the residual = the block input: this wave's output row pieces of the x tile, kept in registers so
+    // that the tile buffer can take the next tile as soon as conv1 is through
+    half8 rv[kNIT];
+#pragma unroll
+    for (int it = 0; it < kNIT; ++it) rv[it] = *reinterpret_cast<const half8*>(xb + xoff[it]);
+
+    // ------------------------------- conv1 -------------------------------
+    float4v acc1[kMT][kNT1];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kNT1; ++nt) acc1[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    kloop(wts, xb, pix1, toff1, acc1, std::integral_constant<int, kNT1>());
+    // ---- epilogue A: BN1 + ReLU -> fp16 rows of the mid tile ----
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int re = lane_e & 15, ge = lane_e >> 4;
+#pragma unroll
+      for (int nt = 0; nt < kNT1; ++nt) {
+        const int p = (wv * kNT1 + nt) * 16 + re;
+        const int my = p / kMW, mx = p - my * kMW;
+        const int iy = py0 - 1 + my, ix = px0 - 1 + mx;
+        const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          const float4v v = acc1[m][nt];
+          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
+          lo = __builtin_elementwise_fma(lo, float2v{al1[m][0], al1[m][1]}, float2v{be1[m][0], be1[m][1]});
+          hi = __builtin_elementwise_fma(hi, float2v{al1[m][2], al1[m][3]}, float2v{be1[m][2], be1[m][3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+          half4 o{olo[0], olo[1], ohi[0], ohi[1]};
+          short4v b = __builtin_bit_cast(short4v, o);
+          b = b & ~(b >> 15);
+          if (!inside) b = b ^ b;
+          if (p < kMH * kMW)
+            *reinterpret_cast<short4v*>(mid + p * kPS + m * 32 + ge * 8) = b;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // incl. the rv reads of the x tile
+    }
+#pragma unroll
+    for (int it = 0; it < kNIT; ++it) asm volatile("" : "+v"(rv[it]));   // rv is complete before the buffer is handed back
+
+    // ------------------------------- conv2 -------------------------------
+    RTPE_BBARRIER();                                     // A2: mid tile complete, x buffer free
+    float4v acc2[kMT][kNT2];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kNT2; ++nt) acc2[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    kloop(wts + 2 * kWSlot, mid, pix2, toff2, acc2, std::integral_constant<int, kNT2>());
+    // ---- epilogue B: BN2, transposed through the (now free) mid tile, + x, ReLU, store ----
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int re = lane_e & 15, ge = lane_e >> 4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RTPE_BBARRIER();                                   // E2: every wave is done reading the mid tile
+      char* obuf = mid + wv * (kNT2 * 16 * kRowB);
+#pragma unroll
+      for (int nt = 0; nt < kNT2; ++nt)
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          const float4v v = acc2[m][nt];
+          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
+          lo = __builtin_elementwise_fma(lo, float2v{al2[m][0], al2[m][1]}, float2v{be2[m][0], be2[m][1]});
+          hi = __builtin_elementwise_fma(hi, float2v{al2[m][2], al2[m][3]}, float2v{be2[m][2], be2[m][3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
+        }
+      half8 ov[kNIT];
+#pragma unroll
+      for (int it = 0; it < kNIT; ++it) ov[it] = *reinterpret_cast<const half8*>(obuf + eoff[it]);
+      const int hy = a.H - py0, hx = a.W - px0;
+      char* const yb = reinterpret_cast<char*>(a.y + (((size_t)n * a.H + py0) * a.W + px0) * a.out_ld);
+      const uint32_t ld2 = (uint32_t)a.out_ld * 2u, row_pix = (uint32_t)a.W & 0xffffffu;
+#pragma unroll
+      for (int it = 0; it < kNIT; ++it) {
+        int e = epos[it];
+        asm volatile("" : "+v"(e));
+        half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
+        short8 b = __builtin_bit_cast(short8, v);
+        b = b & ~(b >> 15);
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx) {
+          const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
+          *reinterpret_cast<short8*>(yb + __umul24(pix, ld2) + ((uint32_t)e & 255u)) = b;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 bool conv_block_supports(int cin, int cout, int H, int W) { return cin == 48 && cout == 48 && H >= kTH && W >= 16; }
 
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,
@@ -418,9 +705,14 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   RTPE_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= 48 && out_ld >= 48 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
                "basic block: NHWC views must be 16-byte aligned (in_ld=%d out_ld=%d)", in_ld, out_ld);
   RTPE_REQUIRE(x_bytes > 0 && x_bytes < 0x80000000ull, "basic block: input view of %zu bytes", x_bytes);
+  // option "block_ring" (or RTPE_BLOCK_RING=1): the variant that streams the weights through a 3-slot ring
+  // (bit-identical results; kept for A/B measurements in one process)
+  const int ring = get_option(kOptBlockRing);
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_rw_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   BlockArgs a;
@@ -435,7 +727,10 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
   long G = 32;                                            // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
-  hipLaunchKernelGGL(conv_block_kernel, dim3((unsigned)(8 * G)), dim3((kWaves + kLoad) * 64), kLds, s, a);
+  if (ring)
+    hipLaunchKernelGGL(conv_block_kernel, dim3((unsigned)(8 * G)), dim3((kWaves + kLoad) * 64), kLds, s, a);
+  else
+    hipLaunchKernelGGL(conv_block_rw_kernel, dim3((unsigned)(8 * G)), dim3((kWaves + kLoad) * 64), kLdsRW, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;
 }

@@ -61,6 +61,31 @@ struct rtpe_hrnet {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+namespace rtpe {
+static int g_options[kNumOptions] = {-1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "", "", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "", "", ""};
+int get_option(int key) {
+  int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
+  if (v < 0) {
+    v = kOptionEnv[key][0] ? env_int(kOptionEnv[key], 0) : 0;
+    __atomic_store_n(&g_options[key], v, __ATOMIC_RELAXED);
+  }
+  return v;
+}
+}  // namespace rtpe
+
+extern "C" int rtpe_set_option(const char* name, int32_t value) {
+  RTPE_REQUIRE(name != nullptr && value >= 0, "set_option: bad argument");
+  for (int k = 0; k < kNumOptions; ++k)
+    if (kOptionNames[k][0] && strcmp(name, kOptionNames[k]) == 0) {
+      __atomic_store_n(&g_options[k], (int)value, __ATOMIC_RELAXED);
+      return RTPE_OK;
+    }
+  set_error("set_option: unknown option '%s'", name);
+  return RTPE_E_INVALID;
+}
+
 extern "C" const char* rtpe_last_error_string(void) { return g_err.c_str(); }
 extern "C" int rtpe_version(void) { return 1; }
 extern "C" int rtpe_device_count(void) {

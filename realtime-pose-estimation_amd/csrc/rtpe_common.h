@@ -44,6 +44,10 @@ inline int env_int(const char* name, int dflt) {
 #define RTPE_DIAG_ENV_INT(name, dflt) (dflt)
 #endif
 
+// run-time tuning options (rtpe_set_option): every setting gives bit-identical results
+enum { kOptBlockRing = 0, kNumOptions = 4 };
+int get_option(int key);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
 // launcher runs on the CURRENT device (one mask per kernel template instance)
 inline bool first_use_on_device(unsigned long long* mask) {
