@@ -279,6 +279,17 @@ int rtpe_warp_normalize(const void* src_hwc_u8, int32_t h, int32_t w, int32_t st
                         const float* m_dst_to_src, const float* mean, const float* stdev,
                         void* dst_chw_f32, int32_t oh, int32_t ow, int32_t round_u8, void* stream);
 
+/* One step of the multi-scale / flip test aggregation (upstream HigherHRNet core/inference.py
+ * get_multi_stage_outputs / aggregate_results, called from legacy/valid_ae1dim.py:166-207):
+ *     dst = [dst +] resize( flip_w( src[:, channel_map] ) )  [/ div]
+ * src (N,C_src,h,w), dst (N,C_dst,oh,ow) fp32 NCHW on the device; resize = F.interpolate(mode="bilinear",
+ * align_corners=False) (identity when the sizes agree); channel_map: C_dst HOST ints (NULL = identity; <= 64
+ * channels), e.g. the COCO flip index; flip_w: torch.flip(., [3]) of the resized map; accumulate != 0: add to
+ * dst; div != 1: true division of the result.  Bit-equal to the torch ops on the CPU.  Stream-ordered. */
+int rtpe_resize_combine(const float* src, int32_t N, int32_t C_src, int32_t h, int32_t w,
+                        const int32_t* channel_map, int32_t C_dst, int32_t flip_w, float* dst,
+                        int32_t oh, int32_t ow, int32_t accumulate, float div, void* stream);
+
 /* F.interpolate(mode="bilinear", align_corners=True), fp32 NCHW planes.
  * validate_hhrnet.py:94-98.  src (planes,h,w) -> dst (planes,oh,ow). */
 int rtpe_bilinear_upsample(const float* src, int32_t planes, int32_t h, int32_t w,

@@ -71,6 +71,8 @@ struct BlockArgs {
   int tiles_x, tiles_y;
   FastDiv div_tiles_x, div_tiles_xy;
   int x_bytes;
+  int ablate;               // -DRTPE_DIAG builds only (RTPE_BLOCK_ABL): 1 no x-tile reloads, 2 no epilogue A, 4 no output
+                            // stores, 8 no k-loops - wrong results, timing only
 };
 
 __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const BlockArgs a) {
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this loader's rows of tile u (and weights) have landed
       RTPE_BBARRIER();                                   // M
       RTPE_BBARRIER();                                   // A2: conv1 has read the tile, residual pieces are in registers
-      if (u + 1 < U) issue(u + 1);
+      if (u + 1 < U && !(a.ablate & 1)) issue(u + 1);
       RTPE_BBARRIER();                                   // E2
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,28 +510,32 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
 
   // -------------------------------- MFMA waves --------------------------------
   const int r = lane & 15, g = lane >> 4;
-  int toff1[2 * kKH], toff2[2 * kKH];
+  // LDS address of the B operand of k-step k = a per-lane base + a compile-time immediate (koff below): no
+  // address arithmetic in the k-loops.  k = 32 k-values of the flat [tap][48 channels] order, 8 per lane
+  // group g; 48 = 32 + 16, so the pattern repeats every 3 k-steps: for k % 3 = 0 / 2 all four groups sit in
+  // one tap (offset = tap offset + {0, 32} + 16 g); for k % 3 = 1 groups 2, 3 have moved on to the next tap,
+  // which is the next pixel of the row (96 bytes on: the same formula) except at the end of a tap row (k = 4:
+  // + (row pitch - 3 pixels)) and in the zero-weight k padding (k = 13: any finite in-tile data - tap 0).
+  // Three base registers per pixel tile cover the three cases.
+  int b1a[kNT1], b1b[kNT1], b1c[kNT1], b2a[kNT2], b2b[kNT2], b2c[kNT2];
+  {
+    const int hi = g >= 2 ? 1 : 0;
 #pragma unroll
-  for (int k = 0; k < 2 * kKH; ++k) {
-    int kk = k * 32 + g * 8;
-    if (kk >= 9 * 48) kk -= 9 * 48;
-    const int tap = kk / 48, c = kk - tap * 48;
-    const int ty = tap / 3, tx = tap - ty * 3;
-    toff1[k] = (ty * kXW + tx) * kPS + c * 2;
-    toff2[k] = (ty * kMW + tx) * kPS + c * 2;
-  }
-  int pix1[kNT1], pix2[kNT2];
+    for (int nt = 0; nt < kNT1; ++nt) {
+      int p = (wv * kNT1 + nt) * 16 + r;
+      p = p < kMH * kMW ? p : kMH * kMW - 1;               // idle slots recompute the last pixel
+      const int my = p / kMW, mx = p - my * kMW;
+      b1a[nt] = (int)(4 * kWSlot) + (my * kXW + mx) * kPS + g * 16;     // x tile at smem + 4 * kWSlot
+      b1b[nt] = b1a[nt] + hi * (kXW - 3) * kPS;
+      b1c[nt] = b1a[nt] - hi * ((2 * kXW + 2) * kPS + 96);
+    }
 #pragma unroll
-  for (int nt = 0; nt < kNT1; ++nt) {
-    int p = (wv * kNT1 + nt) * 16 + r;
-    p = p < kMH * kMW ? p : kMH * kMW - 1;
-    const int my = p / kMW, mx = p - my * kMW;
-    pix1[nt] = (my * kXW + mx) * kPS;
-  }
-#pragma unroll
-  for (int nt = 0; nt < kNT2; ++nt) {
-    const int p = (wv * kNT2 + nt) * 16 + r;
-    pix2[nt] = ((p >> 5) * kMW + (p & 31)) * kPS;
+    for (int nt = 0; nt < kNT2; ++nt) {
+      const int p = (wv * kNT2 + nt) * 16 + r;
+      b2a[nt] = (int)(4 * kWSlot + kXBytes) + ((p >> 5) * kMW + (p & 31)) * kPS + g * 16;   // mid tile
+      b2b[nt] = b2a[nt] + hi * (kMW - 3) * kPS;
+      b2c[nt] = b2a[nt] - hi * ((2 * kMW + 2) * kPS + 96);
+    }
   }
   float4v al1[kMT], be1[kMT], al2[kMT], be2[kMT];
 #pragma unroll
@@ -558,15 +564,21 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
   }
 
   // one conv: 14 k-steps straight through (no hand-over in the middle: the weights are resident)
-  auto kloop = [&](const char* wbase, const char* tile, const int* pix, const int* toff, auto acc, auto ntc)
+  auto kloop = [&](const char* wbase, const int* ba, const int* bb, const int* bc, auto acc, auto ntc, auto pitch)
       __attribute__((always_inline)) {
-    constexpr int NT = decltype(ntc)::value;
+    constexpr int NT = decltype(ntc)::value, RW = decltype(pitch)::value;
     const char* wl = wbase + lane * 16;
+    // byte offset of k-step k for lane group 0 (see the base registers above)
+    auto koff = [](int k) constexpr { const int tap = (32 * k) / 48; return ((tap / 3) * RW + tap % 3) * kPS + ((32 * k) % 48) * 2; };
+    auto bptr = [&](int k, int nt) __attribute__((always_inline)) {
+      const int base = k == 4 ? bb[nt] : k == 13 ? bc[nt] : ba[nt];
+      return reinterpret_cast<const half8*>(smem + base + koff(k));
+    };
     half8 af[2][kMT], bf[2][NT];
 #pragma unroll
     for (int m = 0; m < kMT; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const half8*>(tile + pix[nt] + toff[0]);
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *bptr(0, nt);
 #pragma unroll
     for (int kk = 0; kk < 2 * kKH; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
@@ -574,7 +586,7 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
 #pragma unroll
         for (int m = 0; m < kMT; ++m) af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 1) * kMT + m) * 1024);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nxt][nt] = *reinterpret_cast<const half8*>(tile + pix[nt] + toff[kk + 1]);
+        for (int nt = 0; nt < NT; ++nt) bf[nxt][nt] = *bptr(kk + 1, nt);
       }
 #pragma unroll
       for (int m = 0; m < kMT; ++m)
@@ -583,10 +595,9 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc[m][nt], 0, 0, 0);
       if (kk + 1 < 2 * kKH) {
 #pragma unroll
-        for (int i = 0; i < (kMT + NT + 3) / 4; ++i) {
+        for (int i = 0; i < (kMT + NT + 1) / 2; ++i) {                               // two reads per MFMA, early in the step
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -611,9 +622,9 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
     for (int m = 0; m < kMT; ++m)
 #pragma unroll
       for (int nt = 0; nt < kNT1; ++nt) acc1[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
-    kloop(wts, xb, pix1, toff1, acc1, std::integral_constant<int, kNT1>());
+    if (!(a.ablate & 8)) kloop(wts, b1a, b1b, b1c, acc1, std::integral_constant<int, kNT1>(), std::integral_constant<int, kXW>());
     // ---- epilogue A: BN1 + ReLU -> fp16 rows of the mid tile ----
-    {
+    if (!(a.ablate & 2)) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       const int re = lane_e & 15, ge = lane_e >> 4;
@@ -652,7 +663,7 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
     for (int m = 0; m < kMT; ++m)
 #pragma unroll
       for (int nt = 0; nt < kNT2; ++nt) acc2[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
-    kloop(wts + 2 * kWSlot, mid, pix2, toff2, acc2, std::integral_constant<int, kNT2>());
+    if (!(a.ablate & 8)) kloop(wts + 2 * kWSlot, b2a, b2b, b2c, acc2, std::integral_constant<int, kNT2>(), std::integral_constant<int, kMW>());
     // ---- epilogue B: BN2, transposed through the (now free) mid tile, + x, ReLU, store ----
     {
       int lane_e = lane;
@@ -687,7 +698,7 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
         half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
         short8 b = __builtin_bit_cast(short8, v);
         b = b & ~(b >> 15);
-        if ((e >> 16) < hy && ((e >> 8) & 255) < hx) {
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx && !(a.ablate & 4)) {
           const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
           *reinterpret_cast<short8*>(yb + __umul24(pix, ld2) + ((uint32_t)e & 255u)) = b;
         }
@@ -724,6 +735,8 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   a.div_tiles_x = make_fastdiv(a.tiles_x);
   a.div_tiles_xy = make_fastdiv(a.tiles_x * a.tiles_y);
   a.x_bytes = (int)x_bytes;
+  static const int abl = RTPE_DIAG_ENV_INT("RTPE_BLOCK_ABL", 0);
+  a.ablate = abl;
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
   long G = 32;                                            // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;

@@ -834,6 +834,108 @@ def test_two_bundled_images_end_to_end(nat, teacher, golden_dir, name, shape, va
 
 
 # --------------------------------------------------------------------------- #
+# row 8f-4: multi-scale / flip test aggregation (legacy/valid_ae1dim.py:166-207 + upstream core/inference.py)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("case", [((40, 56), (80, 112)), ((80, 112), (80, 112)), ((80, 112), (160, 217)),
+                                  ((160, 224), (97, 131)), ((320, 448), (80, 112)), ((17, 23), (5, 9))])
+def test_resize_combine_is_bit_equal_to_the_torch_ops(nat, case):
+    """one kernel = interpolate(align_corners=False) [+ flip + channel index] [+ add] [/ div]: against the stock
+    torch ops on the CPU, bit for bit, up- and down-scaling, odd sizes"""
+    from rtpe.inference import FLIP_CONFIG, resize_combine
+    (h, w), (oh, ow) = case
+    g = torch.Generator().manual_seed(h * 31 + ow)
+    x = torch.randn(2, 34, h, w, generator=g)
+    xd = x.to("cuda:0")
+    want = F.interpolate(x, (oh, ow), mode="bilinear", align_corners=False)
+    assert torch.equal(resize_combine(xd, (oh, ow)).cpu(), want)
+    perm = FLIP_CONFIG["COCO"]
+    want2 = torch.flip(want, [3])[:, :17][:, perm]
+    assert torch.equal(resize_combine(xd, (oh, ow), perm, flip=True).cpu(), want2)
+    acc = torch.randn(2, 17, oh, ow, generator=g)
+    accd = acc.to("cuda:0")
+    resize_combine(xd, (oh, ow), [17 + p for p in perm], flip=True, out=accd, accumulate=True, div=3.0)
+    want3 = (acc + torch.flip(want, [3])[:, 17:][:, perm]) / 3.0
+    assert torch.equal(accd.cpu(), want3)
+
+
+@pytest.mark.parametrize("flip,project,scales", [(True, True, (1,)), (True, True, (0.5, 1, 2)), (False, False, (0.5, 1)),
+                                                 (True, False, (1, 2))])
+def test_multi_scale_aggregation_equals_the_torch_restatement(nat, flip, project, scales):
+    """get_multi_stage_outputs + aggregate_results on the GPU against the torch-CPU restatement of the upstream
+    functions, bit for bit, with a stand-in model that returns fixed two-stage maps of the right shapes"""
+    from oracle import inference_ref
+    from rtpe import inference
+    base = (448, 320)                                      # (w, h) at scale 1
+    g = torch.Generator().manual_seed(7)
+    store = {}
+    for s in scales:
+        H, W = int(base[1] * s / min(scales)) // 4 * 4, int(base[0] * s / min(scales)) // 4 * 4
+        store[s] = [(torch.randn(1, 34, H // 4, W // 4, generator=g), torch.randn(1, 17, H // 2, W // 2, generator=g))
+                    for _ in range(2)]
+
+    def make_model(device):
+        calls = {"n": 0}
+
+        def model(image):
+            s = float(image[0, 0, 0, 0].item())               # the fake input carries its scale
+            k = calls["n"] % 2 if flip else 0
+            calls["n"] += 1
+            return [t.to(device) for t in store[s][k]]
+        return model
+    inputs_c = {s: torch.full((1, 3, 8, 8), float(s)) for s in scales}
+    want_hm, want_tags = inference_ref.multi_scale_maps(make_model("cpu"), inputs_c, scales, base, flip, project)
+    model = make_model("cuda:0")
+    final, tags_list = None, []
+    for s in sorted(scales, reverse=True):
+        _, hms, tags = inference.get_multi_stage_outputs(model, inputs_c[s].to("cuda:0"), flip, project, base)
+        final, tags_list = inference.aggregate_results(s, final, tags_list, hms, tags, scales, flip, project)
+    if len(scales) != 1:
+        final = inference.resize_combine(final, final.shape[2:], div=float(len(scales)))
+    got_tags = torch.cat(tags_list, dim=4)
+    assert final.shape == want_hm.shape and got_tags.shape == want_tags.shape
+    assert torch.equal(final.cpu(), want_hm) and torch.equal(got_tags.cpu(), want_tags)
+
+
+def test_multi_scale_flip_inference_end_to_end(nat, teacher):
+    """valid_ae1dim.py:166-207 with the real teacher (W0), two scales + flip, on a small image: maps against the
+    torch restatement fed with the GPU's own network outputs (bit-equal), decode against the oracle's parse of those
+    maps (tag dimension 2), keypoints mapped back to image coordinates"""
+    from oracle import inference_ref
+    from rtpe import inference
+    from rtpe.third_party import transforms
+    from rtpe.third_party.group import HeatmapParser
+    m, sd = teacher("W0")
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)
+    scales = (1, 2)
+    parser = HeatmapParser(17, 30, 0.1, 1.0, True, False)
+    final_results, scores, final_hm, tags = inference.multi_scale_inference(m, parser, img, 128, scales, True, True,
+                                                                            device="cuda:0")
+    base_size, center, scale = transforms.get_multi_scale_size(img, 128, 1.0, 1)
+    assert tuple(final_hm.shape) == (1, 17, base_size[1], base_size[0]) and tags.shape[-1] == 2
+    cache = {}
+
+    def cpu_model(image):                                   # the GPU teacher's outputs, moved to the CPU
+        import hashlib
+        key = hashlib.md5(image.contiguous().numpy().tobytes()).hexdigest()      # the mirrored input is another key
+        if key not in cache:
+            with torch.no_grad():
+                cache[key] = [t.cpu() for t in m(image.to("cuda:0"))]
+        return [t.clone() for t in cache[key]]
+    inputs = {s: transforms.warp_normalize(img, 128, s, 1, device="cuda:0")[0].cpu() for s in scales}
+    want_hm, want_tags = inference_ref.multi_scale_maps(cpu_model, inputs, scales, base_size, True, True)
+    assert torch.equal(final_hm.cpu(), want_hm) and torch.equal(tags.cpu(), want_tags)
+    want, wsc = decode_ref.HeatmapParserRef().parse(want_hm, want_tags)
+    got, gsc = parser.parse(final_hm, tags)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(np.array(gsc, np.float32), np.array(wsc, np.float32))
+    assert len(final_results) == len(want[0])
+    if len(want[0]):
+        back = transforms.get_final_preds(want, center, scale, [want_hm.size(3), want_hm.size(2)])
+        np.testing.assert_allclose(np.stack(final_results), np.stack(back), rtol=0, atol=0)
+
+
+# --------------------------------------------------------------------------- #
 # config 5: the dual-head student
 # --------------------------------------------------------------------------- #
 def test_student_vs_golden_and_oracle(nat, golden_dir):
