@@ -66,7 +66,7 @@ int rtpe_device_count(void);
 #define RTPE_OP_STEM 0   /* 3x3 s2 conv Cin=3 + BN + ReLU from the NCHW input;
                             pose_higher_hrnet.py:363-365,638-640 + tofp16
                             (fp16_utils/fp16util.py:50-51)                    */
-#define RTPE_OP_CONV 1   /* kxk (1|3) stride (1|2) conv + BN/bias [+residual]
+#define RTPE_OP_CONV 1   /* kxk (1|3|5) stride (1|2) conv + BN/bias [+residual]
                             [+ReLU]; BasicBlock :46-75, Bottleneck :78-116,
                             transitions :548-583, fuse convs :200-230,
                             final_layers :460-482                            */
@@ -87,6 +87,16 @@ int rtpe_device_count(void);
 #define RTPE_OP_SIGMOID_ADD 8 /* y = res + sigmoid(in[...,0] / 20) broadcast over
                                  channels, students.py:755-756; the sigmoid map is
                                  NCHW output 0 when RTPE_F_OUT_PREDS is set     */
+
+#define RTPE_OP_AUX_PACK 9    /* the SECOND network input (AttentionStudentSteps' `alt` image in LAB / HSV,
+                                 students.py:980-1002): (N,3,H,W) fp32 NCHW -> fp32 NHWC with 4 channels
+                                 (one zero pad) at full resolution                */
+#define RTPE_OP_RESIZE 10     /* F.interpolate(in, size of out, mode="bilinear") (align_corners=False) of cout
+                                 channels, fp32 NHWC -> channels [out_coff, out_coff+cout) of out;
+                                 students.py:996-1000                             */
+#define RTPE_OP_GATE_MUL 11   /* y[..., :cout] = res[..., :cout] * sigmoid(in[..., 0] / d), d = the fp32 whose bits
+                                 are reserved[0] (0: no division), students.py:1012-1040; the sigmoid map is
+                                 NCHW output 0 when RTPE_F_OUT_PREDS is set       */
 
 /* op flags */
 #define RTPE_F_RELU 1
@@ -198,6 +208,19 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
  * variants for A/B measurements in one process).  "block_ring" = 1: the fused BasicBlock kernel streams its
  * weights through a 3-slot LDS ring instead of keeping them resident (default 0; env RTPE_BLOCK_RING). */
 int rtpe_set_option(const char* name, int32_t value);
+
+/* rtpe_hrnet_forward for a program with a second input (RTPE_OP_AUX_PACK): aux = (N,3,H,W) fp32 NCHW on the
+ * device (AttentionStudentSteps.forward(x, alt=...), students.py:966).  Everything else as rtpe_hrnet_forward. */
+int rtpe_hrnet_forward_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const void* aux_nchw_f32,
+                           int32_t N, int32_t H, int32_t W, void* preds, void* refined, int32_t out_dtype,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* RGB -> CIE-LAB (D65, 2 degree observer) or HSV, the two `alt_colorspace` choices of the reference's
+ * CocoDistillationDatasetAugmented2 (rtpe/dataloaders.py:314-375, which calls skimage.color.rgb2lab / rgb2hsv on
+ * the ToTensor'd image).  src: (N,3,H,W) fp32 in [0,1]; dst: same shape; mode 0 = LAB (L in [0,100]), 1 = HSV
+ * (all in [0,1]).  The published scikit-image formulas in fp32 (parity unpinned: skimage is not in the image). */
+int rtpe_rgb_to_alt(const float* src_nchw, int32_t N, int32_t H, int32_t W, int32_t mode, float* dst_nchw,
+                    void* stream);
 
 /* Tuned launch shapes of (N,H,W) as plain integers, so that a caller can keep them across
  * processes (the reference's cudnn.benchmark has to re-tune in every process).

@@ -6,7 +6,8 @@
 // with resize = F.interpolate(mode="bilinear", align_corners=False) (or the identity when the sizes agree) and
 // flip_w = torch.flip(., [3]) applied AFTER the resize, as upstream does.  One kernel does exactly that, with
 // PyTorch-CPU's arithmetic so that results are bit-equal to the torch ops (compiled with -ffp-contract=off):
-//   * source index  real = scale * (o + 0.5) - 0.5, clamped at 0, scale = float(in) / float(out);
+//   * source index  real = fma(scale, o + 0.5, -0.5) (ATen's CPU build contracts the expression; found by
+//     experiment against F.interpolate), clamped at 0, scale = float(in) / float(out);
 //     i0 = floor(real), i1 = i0 + (i0 < in - 1), l1 = real - i0, l0 = 1 - l1   (area_pixel_compute_source_index);
 //   * value  T = fma(v0, lx0, v1 * lx1) per row, out = fma(T0, ly0, T1 * ly1)   (the order the decode kernels
 //     pin for align_corners=True, csrc/decode.hip);
@@ -30,7 +31,7 @@ struct ResizeArgs {
 
 __device__ __forceinline__ void axis_nc(float scale, int n_in, int n_out, int o, int* i0, int* i1, float* l0, float* l1) {
   if (n_in == n_out) { *i0 = *i1 = o; *l0 = 1.f; *l1 = 0.f; return; }
-  float real = scale * ((float)o + 0.5f) - 0.5f;
+  float real = __builtin_fmaf(scale, (float)o + 0.5f, -0.5f);   // ATen's build contracts scale * (o + 0.5) - 0.5
   real = real < 0.f ? 0.f : real;
   int a = (int)real;
   a = a < n_in - 1 ? a : n_in - 1;

@@ -32,7 +32,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-constexpr int kTapTableBytes = 1024;
+constexpr int kTapTableBytes = 2048;      // 4 ints per k chunk: up to 128 k chunks (5x5 taps x 64 fp32 channels = 100)
 
 __device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }
 
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     if (kk >= kvalid) kk -= kvalid;  // zero-weight padding: any finite in-tile data will do
     const int tap = fdiv(kk, a.div_cc);
     const int c = kk - tap * a.cc;
-    const int tyy = (a.tapw == 3) ? (tap * 11 >> 5) : (a.tapw == 2 ? (tap >> 1) : 0);
+    const int tyy = (a.tapw == 3) ? (tap * 11 >> 5) : (a.tapw == 2 ? (tap >> 1) : (a.tapw == 5 ? (tap * 13 >> 6) : 0));
     const int txx = tap - tyy * a.tapw;
     tapoff[i] = (tyy * a.dil * a.halo_w + txx * a.dil) * a.pstride + c * ES;
   }

@@ -119,7 +119,7 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     o.n_geom = 0;
     const rtpe_op_desc& d = o.d;
     auto bad_t = [&](int t) { return t < 0 || t >= n_tensors; };
-    if (d.kind != RTPE_OP_FUSE && d.kind != RTPE_OP_STEM && bad_t(d.in_t)) {
+    if (d.kind != RTPE_OP_FUSE && d.kind != RTPE_OP_STEM && d.kind != RTPE_OP_AUX_PACK && bad_t(d.in_t)) {
       set_error("op %d: bad input tensor", i); delete h; return RTPE_E_INVALID;
     }
     if (bad_t(d.out_t) && !(d.flags & RTPE_F_NO_NHWC)) {
@@ -159,10 +159,14 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
       o.w_dev_off[0] = off;
       off = align_up(off + wbytes, 256);
     } else if (d.kind == RTPE_OP_CAST || d.kind == RTPE_OP_AVGPOOL || d.kind == RTPE_OP_CAM_COMBINE ||
-               d.kind == RTPE_OP_SIGMOID_ADD) {
+               d.kind == RTPE_OP_SIGMOID_ADD || d.kind == RTPE_OP_RESIZE || d.kind == RTPE_OP_GATE_MUL) {
       if ((d.kind == RTPE_OP_CAM_COMBINE && (bad_t(d.res_t) || bad_t(d.term_t[0]))) ||
-          (d.kind == RTPE_OP_SIGMOID_ADD && bad_t(d.res_t))) {
+          ((d.kind == RTPE_OP_SIGMOID_ADD || d.kind == RTPE_OP_GATE_MUL) && bad_t(d.res_t))) {
         set_error("op %d: missing operand tensor", i); delete h; return RTPE_E_INVALID;
+      }
+    } else if (d.kind == RTPE_OP_AUX_PACK) {
+      if (h->tensors[d.out_t].reserved != 4 || h->tensors[d.out_t].channels < 4) {
+        set_error("op %d: the packed second input must be an fp32 tensor of >= 4 channels", i); delete h; return RTPE_E_INVALID;
       }
     } else {
       set_error("op %d: unknown kind %d", i, d.kind); delete h; return RTPE_E_INVALID;
@@ -353,7 +357,7 @@ static int read_op_times(const rtpe_hrnet* h, const Events& ev, bool fused_mode,
 static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
                int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms,
                int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
-               std::vector<hipEvent_t>* rec = nullptr) {
+               std::vector<hipEvent_t>* rec = nullptr, const void* aux = nullptr) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
   // kernels, events and function attributes act on HIP's CURRENT device: make the handle's device current for
   // the call (the stream and every buffer must belong to it) and give the caller's device back afterwards
@@ -485,6 +489,30 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
         rc = conv_launch(o.plan[k], tile, a, s);
       }
+    } else if (d.kind == RTPE_OP_AUX_PACK) {
+      if (aux == nullptr) { set_error("forward: this program has a second input (use rtpe_hrnet_forward_aux)"); return RTPE_E_INVALID; }
+      const rtpe_tensor_desc& to = h->tensors[d.out_t];
+      rc = aux_pack_launch(reinterpret_cast<const float*>(aux), reinterpret_cast<float*>(tptr(d.out_t, d.out_coff)),
+                           to.channels, N, H >> to.ds_log2, W >> to.ds_log2, s);
+    } else if (d.kind == RTPE_OP_RESIZE) {
+      const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+      const rtpe_tensor_desc& to = h->tensors[d.out_t];
+      rc = resize_nhwc_launch(reinterpret_cast<const float*>(tptr(d.in_t, d.in_coff)), ti.channels, H >> ti.ds_log2,
+                              W >> ti.ds_log2, reinterpret_cast<float*>(tptr(d.out_t, d.out_coff)), to.channels,
+                              H >> to.ds_log2, W >> to.ds_log2, d.cout, N, s);
+    } else if (d.kind == RTPE_OP_GATE_MUL) {
+      const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+      const rtpe_tensor_desc& to = h->tensors[d.out_t];
+      const size_t pixels = (size_t)N * (H >> ti.ds_log2) * (W >> ti.ds_log2);
+      float* att_out = (d.flags & RTPE_F_OUT_PREDS) ? reinterpret_cast<float*>(preds) : nullptr;
+      if ((d.flags & RTPE_F_OUT_PREDS) && (!preds || out_dtype != RTPE_DTYPE_F32)) {
+        set_error("forward: the sigmoid map output must be a float32 buffer"); return RTPE_E_INVALID;
+      }
+      float div;
+      memcpy(&div, &d.reserved[0], sizeof(float));
+      rc = gate_mul_launch(reinterpret_cast<const float*>(tptr(d.in_t, d.in_coff)), ti.channels,
+                           reinterpret_cast<const float*>(tptr(d.res_t, d.res_coff)), h->tensors[d.res_t].channels,
+                           reinterpret_cast<float*>(tptr(d.out_t, d.out_coff)), to.channels, d.cout, pixels, div, att_out, s);
     } else if (d.kind == RTPE_OP_CAST || d.kind == RTPE_OP_AVGPOOL || d.kind == RTPE_OP_SE ||
                d.kind == RTPE_OP_CAM_COMBINE || d.kind == RTPE_OP_SIGMOID_ADD) {
       const rtpe_tensor_desc& ti = h->tensors[d.in_t];
@@ -552,6 +580,14 @@ extern "C" int rtpe_hrnet_forward(rtpe_hrnet* h, const void* x, int32_t x_dtype,
              reinterpret_cast<hipStream_t>(stream), nullptr, 0);
 }
 
+extern "C" int rtpe_hrnet_forward_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const void* aux_nchw_f32, int32_t N,
+                                      int32_t H, int32_t W, void* preds, void* refined, int32_t out_dtype,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  RTPE_REQUIRE(aux_nchw_f32 != nullptr, "forward_aux: the second input is null");
+  return run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes,
+             reinterpret_cast<hipStream_t>(stream), nullptr, 0, -1, -1, nullptr, nullptr, aux_nchw_f32);
+}
+
 extern "C" int rtpe_hrnet_forward_timed(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H,
                                         int32_t W, void* preds, void* refined, int32_t out_dtype,
                                         void* workspace, size_t workspace_bytes, void* stream, float* op_ms,
@@ -575,7 +611,7 @@ extern "C" int rtpe_hrnet_op_cost(const rtpe_hrnet* h, int32_t op, int32_t N, in
   }
   const int cin_logical = d.reserved[0] > 0 ? d.reserved[0] : d.cin;
   if (d.kind >= RTPE_OP_CAST) {                      // small fp32 student ops: bytes only
-    const rtpe_tensor_desc& ti = h->tensors[d.in_t];
+    const rtpe_tensor_desc& ti = h->tensors[d.kind == RTPE_OP_AUX_PACK ? d.out_t : d.in_t];
     const double px = (double)N * (H >> ti.ds_log2) * (W >> ti.ds_log2);
     *bytes = px * ti.channels * 4 * 2;
     return RTPE_OK;
@@ -605,7 +641,7 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
                                    const void* res, void* y, void* stream) {
   RTPE_REQUIRE(x && w_host && alpha_host && beta_host && y, "conv2d_nhwc: null argument");
   const int es = (flags & RTPE_F_F32) ? 4 : 2, eps = 16 / es;
-  RTPE_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin % eps == 0 && cout % eps == 0 &&
+  RTPE_REQUIRE((ksize == 1 || ksize == 3 || ksize == 5) && (stride == 1 || stride == 2) && cin % eps == 0 && cout % eps == 0 &&
                    dilation >= 1 && (dilation == 1 || (ksize == 3 && stride == 1)),
                "conv2d_nhwc: k=%d s=%d d=%d cin=%d cout=%d unsupported", ksize, stride, dilation, cin, cout);
   RTPE_REQUIRE(H % stride == 0 && W % stride == 0, "conv2d_nhwc: H, W must be multiples of the stride");

@@ -212,5 +212,11 @@ int cam_combine_launch(const float* hdc, int hdc_ld, const float* res, int res_l
                        float* y, int out_ld, int C, int N, size_t pix_per_image, hipStream_t s);
 int sigmoid_add_launch(const float* att, int att_ld, const float* x, int x_ld, float* y, int out_ld, int C,
                        size_t pixels, float* att_out, hipStream_t s);
+// y = x * sigmoid(att / div) (div == 0: no division), channels [0, C) of a row
+int gate_mul_launch(const float* att, int att_ld, const float* x, int x_ld, float* y, int out_ld, int C,
+                    size_t pixels, float div, float* att_out, hipStream_t s);
+int aux_pack_launch(const float* aux_nchw, float* y, int out_ld, int N, int H, int W, hipStream_t s);
+int resize_nhwc_launch(const float* x, int in_ld, int Hi, int Wi, float* y, int out_ld, int Ho, int Wo, int C, int N,
+                       hipStream_t s);
 
 }  // namespace rtpe

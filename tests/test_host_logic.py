@@ -472,3 +472,38 @@ def test_configs3_list_over_eight_ranks_gloo(golden_dir):
     assert len(out) == 7
     with pytest.raises(ValueError):
         engine.run_sharded_list(names[:2] + names[:1], lambda part: [(np.array([], np.float32), [])] * len(part), 3, "cpu")
+
+
+def test_student_steps_state_dict_and_program(built, golden_dir):
+    """row 8f-3: AttentionStudentSteps keeps the reference's 340 parameter names / shapes (students.py:786-964) and
+    compiles to one program with a second input"""
+    from rtpe.students import AttentionStudentSteps
+    shapes = json.load(open(os.path.join(golden_dir, "student_steps_shapes.json")))["shapes"]
+    stu = AttentionStudentSteps(None, "cpu", 48, 17, 1, True, None, False).eval()
+    assert {k: list(v.shape) for k, v in stu.state_dict().items()} == shapes and len(shapes) == 340
+    prog = stu.compile_program(("att_divisor", 20.0))
+    kinds = [op.kind for op in prog.ops]
+    assert prog.has_aux and kinds.count(built.OP_AUX_PACK) == 1 and kinds.count(built.OP_RESIZE) == 1
+    assert kinds.count(built.OP_GATE_MUL) == 1 and kinds.count(built.OP_SE) == 6 and kinds.count(built.OP_CAM_COMBINE) == 6
+    assert prog.n_preds == 1 and prog.n_refined == 18 and prog.outputs == [(1, 2), (18, 2)]
+    k5 = [op for op in prog.ops if op.kind == built.OP_CONV and op.ksize == 5]
+    assert len(k5) == 2 and all(op.stride == 2 for op in k5)
+    with pytest.raises(NotImplementedError):
+        AttentionStudentSteps(None, "cpu", 50, 17, 1, True, None, False)
+
+
+def test_alt_colour_space_restatement():
+    """rgb2lab / rgb2hsv of the oracle (published scikit-image formulas) on known colours"""
+    from oracle import student_ref
+    rgb = np.array([[1., 1., 1.], [0., 0., 0.], [1., 0., 0.], [0., 1., 0.], [0., 0., 1.], [0.5, 0.5, 0.5]])
+    lab = student_ref.rgb2lab(rgb)
+    np.testing.assert_allclose(lab[0], [100.0, 0.0, 0.0], atol=2e-2)             # white (D65)
+    np.testing.assert_allclose(lab[1], [0.0, 0.0, 0.0], atol=1e-9)
+    np.testing.assert_allclose(lab[2], [53.24, 80.09, 67.20], atol=2e-2)         # sRGB red
+    np.testing.assert_allclose(lab[4], [32.30, 79.19, -107.86], atol=2e-2)       # sRGB blue
+    np.testing.assert_allclose(lab[5], [53.39, 0.0, 0.0], atol=2e-2)
+    hsv = student_ref.rgb2hsv(rgb)
+    np.testing.assert_allclose(hsv[2], [0.0, 1.0, 1.0])
+    np.testing.assert_allclose(hsv[3], [1 / 3.0, 1.0, 1.0])
+    np.testing.assert_allclose(hsv[4], [2 / 3.0, 1.0, 1.0])
+    np.testing.assert_allclose(hsv[5], [0.0, 0.0, 0.5])

@@ -21,6 +21,7 @@ What gets pinned:
   e2e_640.npz         the same loop body on a synthetic 640x640 input (W0 and W2)
   munkres_vectors.npz Munkres().compute() of the REAL PyPI package on tie-heavy cost matrices
   match_vectors.npz   match_by_tag (group.py:26-97) on that package, tie-heavy candidate tables
+  student_steps.npz   AttentionStudentSteps (students.py:786-1063) outputs + its state-dict contract
 
 ``rtpe/third_party/group.py`` imports the PyPI package ``munkres`` (unpinned, not vendored).  It
 is not installed for this interpreter, but the pure-Python module of munkres 1.1.4 sits in the
@@ -291,6 +292,33 @@ def gen_match(real):
     print("match vectors:", n, "cases; people per case", [len(out["c%d_ans" % i]) for i in range(0, n, 6)])
 
 
+def gen_student_steps(ref):
+    """row 8f-3: AttentionStudentSteps(inplanes=48) (students.py:786-1063), seeded weights, x + alt (a seeded RGB image
+    in LAB, oracle/student_ref.rgb2lab) at 2x3x320x320, att_divisor = 20"""
+    sys.path.insert(0, REF)
+    from rtpe.students import AttentionStudentSteps
+    from oracle import student_ref
+    torch.manual_seed(0)
+    stu = AttentionStudentSteps(None, "cpu", 48, 17, 1, True, None, False).eval()
+    shapes = {k: list(v.shape) for k, v in stu.state_dict().items()}
+    with open(os.path.join(OUT, "student_steps_shapes.json"), "w") as f:
+        json.dump({"n_keys": len(shapes), "shapes": shapes}, f)
+    sd = synth.make_state_dict({k: tuple(v) for k, v in shapes.items()}, 4, "W1")
+    stu.load_state_dict(sd, strict=True)
+    x = synth.make_images(2, 320, 320, seed=77)
+    rgb = torch.rand(2, 3, 320, 320, generator=torch.Generator().manual_seed(78))
+    alt = torch.from_numpy(student_ref.rgb2lab(rgb.permute(0, 2, 3, 1).numpy()).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        att, det = stu(x, alt=alt, att_divisor=20.0)
+        att1, det1 = stu(x, alt=alt)
+    oa, od = student_ref.student_steps_forward(sd, x, alt, 20.0, half_stem=True)
+    print("student steps: keys", len(shapes), "oracle vs reference max diff", float((oa - att).abs().max()),
+          float((od - det).abs().max()), "det range", float(det.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "student_steps.npz"), att=att.numpy(), det=det.numpy(),
+                        att_nodiv_s2=att1.numpy()[:, :, ::2, ::2], det_nodiv_s2=det1.numpy()[:, :, ::2, ::2],
+                        oracle_vs_reference_maxdiff=np.array([float((oa - att).abs().max()), float((od - det).abs().max())]))
+
+
 def gen_base():
     sys.path.insert(0, REF)
     import warnings
@@ -427,7 +455,7 @@ def gen_base():
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="base,w0_640,w2,two_images,e2e,munkres,match")
+    ap.add_argument("--only", default="base,w0_640,w2,two_images,e2e,munkres,match,student_steps")
     only = set(ap.parse_args().only.split(","))
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -435,7 +463,8 @@ def main():
     if "base" in only:
         gen_base()
     ref = Ref()
-    for name, fn in (("w0_640", gen_w0_640), ("w2", gen_w2), ("two_images", gen_two_images), ("e2e", gen_e2e)):
+    for name, fn in (("w0_640", gen_w0_640), ("w2", gen_w2), ("two_images", gen_two_images), ("e2e", gen_e2e),
+                     ("student_steps", gen_student_steps)):
         if name in only:
             fn(ref)
     if "munkres" in only:
