@@ -391,6 +391,7 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
     else if (cin8 % 32 == 0) p.cc = 32;
     else p.cc = round_up(cin8 < 64 ? cin8 : 48, 16);
   }
+  if (p.tapw >= 5 && p.cc > 32) p.cc = 32;              // 25 taps: a stride-2 halo tile of 64 fp32 channels would not fit the LDS
   p.n_cchunks = (cin8 + p.cc - 1) / p.cc;
   p.kc = (p.tapw * p.tapw * p.cc + kch - 1) / kch;
   p.pstride = p.cc * p.esize;
@@ -524,7 +525,7 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
     if (force_nt && c.nt != force_nt) continue;
     if (force_waves && c.waves != force_waves) continue;
     const size_t lds = tile_lds(p, c.th, c.tw, c.waves, c.nt);
-    if ((long)lds > lds_cap && !(c.nt == 2)) continue;
+    if (lds > 160 * 1024 || ((long)lds > lds_cap && !(c.nt == 2))) continue;
     const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw);
     const double waste = (double)tiles * c.th * c.tw / ((double)H_pos * W_pos);
     const long wgs = tiles * N * p.n_cb;
