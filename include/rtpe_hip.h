@@ -226,10 +226,10 @@ int rtpe_rgb_to_alt(const float* src_nchw, int32_t N, int32_t H, int32_t W, int3
  * processes (the reference's cudnn.benchmark has to re-tune in every process).
  * RTPE_TUNED_INTS int32 per (op, parity class), 4 classes per op:
  * {pixel tiles/wave (0 = not tuned), waves, tile_h, tile_w, LDS bytes, kind, workgroups,
- * halo buffer bytes, halo buffers, weight slots, LDS row pitch}.  rtpe_hrnet_tuned_ints gives the array
+ * halo buffer bytes, halo buffers, weight slots}.  rtpe_hrnet_tuned_ints gives the array
  * length.  Import validates every record against the launch shapes this build offers for
  * the op at that shape and changes nothing if any record is foreign (RTPE_E_INVALID). */
-#define RTPE_TUNED_INTS 11
+#define RTPE_TUNED_INTS 10
 int rtpe_hrnet_tuned_ints(const rtpe_hrnet* h, int32_t* count);
 int rtpe_hrnet_export_tuned(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, int32_t* out, int32_t n);
 int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, const int32_t* in, int32_t n);

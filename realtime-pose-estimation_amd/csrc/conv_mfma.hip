@@ -450,12 +450,6 @@ static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
 }
 
 // streaming kernel (conv_stream.hip): one workgroup per CU, 3-slot weight ring + 2-3 halo buffers
-static int stream_pitch(const ConvPlan& p, const TileCand& c, int halo_w) {
-  static const int use = env_int("RTPE_STREAM_PITCH", 1);    // 0: run-time row pitch everywhere (bit-identical results)
-  if (!use || p.in_mul != 1 || p.mt != 3 || c.nt != 5) return 0;
-  return halo_w <= 24 ? 24 : (halo_w <= 44 ? 44 : 0);
-}
-
 static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, ConvTile* out,
                         bool allow_resident = true) {
   // stride 1: 4 or 5 pixel tiles per wave; stride 2 (4x the halo per output pixel): 2, and only with
@@ -464,10 +458,7 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != 2 || p.n_cchunks != 1)) return false;
   const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
   if (hw * 6 > 256) return false;                        // a halo row is at most 4 DMA instructions
-  // the kernel variants of the hot stride-1 shapes (48-cout blocks, 5 pixel tiles per wave) keep the halo rows at a
-  // compile-time pitch, so that the B-operand addresses of the k-loop are a base register + an immediate
-  const int pitch = stream_pitch(p, c, hw);
-  const size_t in_tile = (size_t)hh * (pitch ? pitch : hw) * p.pstride;
+  const size_t in_tile = (size_t)hh * hw * p.pstride;
   const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
   size_t buf = in_tile > out_tile ? in_tile : out_tile;
   buf = (buf + 255) / 256 * 256;
@@ -487,7 +478,6 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   out->nt = c.nt; out->waves = c.waves; out->th = c.th; out->tw = c.tw;
   out->kind = 2; out->grid = (int)(8 * G); out->buf_bytes = (int)buf; out->n_bufs = nb;
   out->n_wslots = nw;
-  out->pitch = pitch;
   out->lds_bytes = conv_stream_lds(p, (int)buf, nb, nw);
   return true;
 }
@@ -580,7 +570,6 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
-  a->pitch = t.pitch;
   static const int abl = RTPE_DIAG_ENV_INT("RTPE_STREAM_ABL", 0);
   a->ablate = abl;
   // ablations for profiling only (-DRTPE_DIAG builds): RTPE_CONV_SKIPK=1 runs the data movement without the k-loops

@@ -130,11 +130,7 @@ constexpr int kResReg0 = 224;
   X(0, 224, 225, 226, 227) X(1, 228, 229, 230, 231) X(2, 232, 233, 234, 235) X(3, 236, 237, 238, 239) \
   X(4, 240, 241, 242, 243) X(5, 244, 245, 246, 247) X(6, 248, 249, 250, 251) X(7, 252, 253, 254, 255)
 
-// PITCH: pixels per halo row in LDS.  0 = the tile's own halo width (run-time offsets: one address add per
-// operand read); 24 / 44 = a compile-time pitch >= the halo width, which turns the B-operand address of k-step k
-// into a per-lane base register + an immediate (see the MFMA waves' setup) at the price of a few unused pixels per
-// row.  Same data, same k order: bit-identical results.
-template <int MT, int NT, int WAVES, int PITCH>
+template <int MT, int NT, int WAVES>
 __global__ void __launch_bounds__((WAVES + kLoaders) * 64) __attribute__((amdgpu_num_vgpr(kResReg0)))
 conv_stream_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -221,7 +217,7 @@ conv_stream_kernel(const ConvArgs a) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const int rowslots = a.halo_w * kSlots;
-    const int rowbytes = (PITCH ? PITCH : a.halo_w) * kPStride;
+    const int rowbytes = a.halo_w * kPStride;
     auto issue = [&](int s, int r0, int r1) {           // halo rows [r0, r1) of the tile of stage s
       int tile, cb;
       um.get(s >> sh, &tile, &cb);
@@ -302,36 +298,22 @@ conv_stream_kernel(const ConvArgs a) {
   const int r = lane & 15;
   const int g = lane >> 4;
   // LDS byte offset of this lane group's 8 channels in k-step k (flat [tap][channel] order)
-  const int row_px = PITCH ? PITCH : a.halo_w;
-  int toff[PITCH ? 1 : kKC];
-  if (!PITCH) {
+  int toff[kKC];
 #pragma unroll
-    for (int k = 0; k < kKC; ++k) {
-      int kk = k * 32 + g * 8;
-      if (kk >= 9 * kCC) kk -= 9 * kCC;                 // zero-weight k padding: any finite in-tile data
-      const int tap = kk / kCC, c = kk - tap * kCC;
-      const int ty = tap / 3, tx = tap - ty * 3;
-      toff[k] = (ty * a.halo_w + tx) * kPStride + c * 2;
-    }
+  for (int k = 0; k < kKC; ++k) {
+    int kk = k * 32 + g * 8;
+    if (kk >= 9 * kCC) kk -= 9 * kCC;                   // zero-weight k padding: any finite in-tile data
+    const int tap = kk / kCC, c = kk - tap * kCC;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    toff[k] = (ty * a.halo_w + tx) * kPStride + c * 2;
   }
-  // With a compile-time pitch the offset of k-step k is base + immediate: k = 32 k-values of the flat
-  // [tap][48 channels] order, 8 per lane group g; 48 = 32 + 16, so for k % 3 = 0 / 2 all four groups sit in one tap
-  // (tap offset + {0, 32} + 16 g); for k % 3 = 1 groups 2, 3 are in the next tap = the next pixel of the row (96 bytes
-  // on: the same formula) except at the end of a tap row (k = 4: + (PITCH - 3) pixels) and in the zero-weight k
-  // padding (k = 13: tap 0).  pixbase holds base a (all k but 4 and 13); pixb / pixc the other two.
-  int pixbase[NT], pixb[PITCH ? NT : 1], pixc[PITCH ? NT : 1];
+  int pixbase[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const uint32_t p = (wv * NT + nt) * 16 + r;
     const uint32_t oy = fdiv(p, a.div_tw);
     const uint32_t ox = p - oy * a.tw;
-    pixbase[nt] = (int)((oy * a.in_mul * row_px + ox * a.in_mul) * kPStride);   // in_mul = conv stride
-    if (PITCH) {
-      const int hi = g >= 2 ? 1 : 0;
-      pixbase[nt] += g * 16;
-      pixb[nt] = pixbase[nt] + hi * (PITCH - 3) * kPStride;
-      pixc[nt] = pixbase[nt] - hi * ((2 * PITCH + 2) * kPStride + 96);
-    }
+    pixbase[nt] = (int)((oy * a.in_mul * a.halo_w + ox * a.in_mul) * kPStride);   // in_mul = conv stride
   }
   constexpr int ROWB = MT * 32 + 16;
   constexpr int CH = MT * 2;
@@ -397,24 +379,10 @@ conv_stream_kernel(const ConvArgs a) {
     constexpr int H = decltype(hsel)::value;
     const char* wl = wslot + lane * 16;
     half8 af[2][MT], bf[2][NT];
-    // B operand of k-step k of pixel tile nt
-    const char* ta[NT];
-    const char* tb[PITCH ? NT : 1];
-    const char* tc[PITCH ? NT : 1];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      ta[nt] = tilebuf + pixbase[nt];
-      if (PITCH) { tb[nt] = tilebuf + pixb[nt]; tc[nt] = tilebuf + pixc[nt]; }
-    }
-    auto koff = [](int k) constexpr { const int tap = (32 * k) / 48; return ((tap / 3) * (PITCH ? PITCH : 1) + tap % 3) * kPStride + ((32 * k) % 48) * 2; };
-    auto bptr = [&](int k, int nt) __attribute__((always_inline)) {
-      if (PITCH) return reinterpret_cast<const half8*>((k == 4 ? tb[nt] : k == 13 ? tc[nt] : ta[nt]) + koff(k));
-      return reinterpret_cast<const half8*>(ta[nt] + toff[PITCH ? 0 : k]);
-    };
 #pragma unroll
     for (int m = 0; m < MT; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *bptr(H * kKH, nt);
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const half8*>(tilebuf + pixbase[nt] + toff[H * kKH]);
 #pragma unroll
     for (int kk = 0; kk < kKH; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
@@ -423,7 +391,8 @@ conv_stream_kernel(const ConvArgs a) {
         for (int m = 0; m < MT; ++m)
           af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 1) * MT + m) * 1024);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nxt][nt] = *bptr(H * kKH + kk + 1, nt);
+        for (int nt = 0; nt < NT; ++nt)
+          bf[nxt][nt] = *reinterpret_cast<const half8*>(tilebuf + pixbase[nt] + toff[H * kKH + kk + 1]);
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -433,19 +402,11 @@ conv_stream_kernel(const ConvArgs a) {
       // the LDS reads of step k+1 (and their address adds) are spread between the MFMAs of step k:
       // the matrix pipe never waits for a burst of reads to be issued
       if (kk + 1 < kKH) {
-        if (PITCH) {
 #pragma unroll
-          for (int i = 0; i < (MT + NT + 1) / 2; ++i) {                            // two reads per MFMA, no address work
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < (MT + NT + 3) / 4; ++i) {                            // four reads per MFMA, early in the step
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     // VALU (address)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                     // DS read
-          }
+        for (int i = 0; i < (MT + NT + 3) / 4; ++i) {                              // four reads per MFMA, early in the step
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                       // VALU (address)
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                       // DS read
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -642,10 +603,10 @@ conv_stream_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, int NT, int WAVES, int PITCH>
+template <int MT, int NT, int WAVES>
 static int launch_stream(const ConvTile& t, const ConvArgs& a, hipStream_t s) {
   static unsigned long long attr_mask = 0;
-  auto kern = conv_stream_kernel<MT, NT, WAVES, PITCH>;
+  auto kern = conv_stream_kernel<MT, NT, WAVES>;
   if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -680,19 +641,14 @@ int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, 
                "streaming conv: LDS layout (%d buffers of %d B, %d weight slots, %zu B)", t.n_bufs, t.buf_bytes,
                t.n_wslots, t.lds_bytes);
   RTPE_REQUIRE(a.halo_w * kSlots <= 256, "streaming conv: halo row of %d pixels", a.halo_w);
-  RTPE_REQUIRE(t.pitch == 0 || ((t.pitch == 24 || t.pitch == 44) && t.pitch >= a.halo_w && p.mt == 3 && t.nt == 5 &&
-                                 p.in_mul == 1), "streaming conv: row pitch %d for a halo of %d pixels", t.pitch, a.halo_w);
-  RTPE_REQUIRE((size_t)a.halo_h * (t.pitch ? t.pitch : a.halo_w) * kPStride <= (size_t)t.buf_bytes &&
+  RTPE_REQUIRE((size_t)a.halo_h * a.halo_w * kPStride <= (size_t)t.buf_bytes &&
                (size_t)t.waves * t.nt * 16 * (p.mt * 32 + 16) <= (size_t)t.buf_bytes, "streaming conv: tile buffer too small");
-#define RTPE_SP(MTv, NTv, Wv, Pv) \
-  if (p.mt == MTv && t.nt == NTv && t.waves == Wv && t.pitch == Pv) return launch_stream<MTv, NTv, Wv, Pv>(t, a, s);
-#define RTPE_S(MTv, NTv, Wv) RTPE_SP(MTv, NTv, Wv, 0)
-  RTPE_SP(3, 5, 4, 24) RTPE_SP(3, 5, 4, 44) RTPE_SP(3, 5, 5, 24) RTPE_SP(3, 5, 5, 44)
+#define RTPE_S(MTv, NTv, Wv) \
+  if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_stream<MTv, NTv, Wv>(t, a, s);
   RTPE_S(3, 4, 4) RTPE_S(3, 5, 4) RTPE_S(3, 5, 5) RTPE_S(3, 2, 4)
   RTPE_S(2, 4, 4) RTPE_S(2, 5, 4) RTPE_S(2, 5, 5)
   RTPE_S(1, 4, 4) RTPE_S(1, 5, 4) RTPE_S(1, 5, 5)
 #undef RTPE_S
-#undef RTPE_SP
   set_error("streaming conv: no kernel variant mt=%d nt=%d waves=%d", p.mt, t.nt, t.waves);
   return RTPE_E_INVALID;
 }

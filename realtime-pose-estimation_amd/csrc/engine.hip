@@ -961,7 +961,7 @@ extern "C" int rtpe_hrnet_export_tuned(const rtpe_hrnet* h, int32_t N, int32_t H
     const ConvTile& t = it->second[i];
     int32_t* r = out + i * RTPE_TUNED_INTS;
     r[0] = t.nt; r[1] = t.waves; r[2] = t.th; r[3] = t.tw; r[4] = (int32_t)t.lds_bytes; r[5] = t.kind;
-    r[6] = t.grid; r[7] = t.buf_bytes; r[8] = t.n_bufs; r[9] = t.n_wslots; r[10] = t.pitch;
+    r[6] = t.grid; r[7] = t.buf_bytes; r[8] = t.n_bufs; r[9] = t.n_wslots;
   }
   return RTPE_OK;
 }
@@ -988,8 +988,7 @@ extern "C" int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int3
       bool found = false;
       for (const ConvTile& c : cands) {
         if (c.nt == r[0] && c.waves == r[1] && c.th == r[2] && c.tw == r[3] && (int32_t)c.lds_bytes == r[4] &&
-            c.kind == r[5] && c.grid == r[6] && c.buf_bytes == r[7] && c.n_bufs == r[8] && c.n_wslots == r[9] &&
-            c.pitch == r[10]) {
+            c.kind == r[5] && c.grid == r[6] && c.buf_bytes == r[7] && c.n_bufs == r[8] && c.n_wslots == r[9]) {
           tiles[i * 4 + k] = c;
           found = true;
           break;

@@ -129,7 +129,6 @@ struct ConvArgs {
   int buf_bytes;         // streaming kernel: bytes of one LDS tile buffer
   int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
   int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
-  int pitch;             // streaming kernel: pixels per halo row in LDS (0: halo_w; 24 / 44: compile-time pitch variants)
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
   unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
@@ -153,7 +152,6 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
   int n_wslots;         // streaming: weight half-stage slots
-  int pitch;            // streaming: LDS halo row pitch in pixels, 0 = halo_w (see conv_stream.hip)
 };
 
 struct ConvGeom {       // logical layer, independent of the batch
