@@ -365,6 +365,12 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
   }
   p.mt = (g.cout % 48 == 0 || g.cout < 48) ? 3 : 4;
   if (g.cout <= 32) p.mt = (g.cout + 15) / 16;
+  // the stride-2 3x3 transition 256 -> 96 (pose_higher_hrnet.py:571-581): its workgroups spend their time staging
+  // (33 x 17)-pixel halo tiles of 4 channel chunks; all 96 output channels in one workgroup stage them once
+  // instead of once per 48-channel block
+  static const int wide = env_int("RTPE_CONV_MT6", 1);
+  if (wide && !dc && g.stride == 2 && g.ksize == 3 && (g.esize == 0 || g.esize == 2) && g.cout == 96 && g.cin >= 128)
+    p.mt = 6;
   p.cout_pad = round_up(g.cout, 16 * p.mt);
   p.n_cb = p.cout_pad / (16 * p.mt);
   const int eps = 16 / (g.esize ? g.esize : 2);          // elements per 16-byte slot
@@ -522,6 +528,7 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   memset(&best, 0, sizeof(best));
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;  // 128 accumulators + operands: keep 2 waves/SIMD
+    if (p.mt == 6 && c.nt != 2) continue;  // the 96-cout variant exists for 2 pixel tiles per wave
     if (force_nt && c.nt != force_nt) continue;
     if (force_waves && c.waves != force_waves) continue;
     const size_t lds = tile_lds(p, c.th, c.tw, c.waves, c.nt);
@@ -603,6 +610,7 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
   }
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;
+    if (p.mt == 6 && c.nt != 2) continue;
     const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                          ((double)H_pos * W_pos);
     if (waste > 1.35 * min_waste) continue;
@@ -649,7 +657,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
     return p.esize == 4 ? launch_variant<float, MTv, NTv, Wv>(t, a, p.n_cb, s)                 \
                         : launch_variant<_Float16, MTv, NTv, Wv>(t, a, p.n_cb, s);
   RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5)
-  RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5)
+  RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5) RTPE_V(6, 2, 4)
   RTPE_V(2, 8, 4) RTPE_V(2, 4, 4) RTPE_V(2, 2, 4) RTPE_V(2, 5, 4) RTPE_V(2, 5, 5)
   RTPE_V(1, 8, 4) RTPE_V(1, 4, 4) RTPE_V(1, 2, 4) RTPE_V(1, 5, 4) RTPE_V(1, 5, 5)
 #undef RTPE_V
