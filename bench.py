@@ -142,7 +142,7 @@ def run_list_mode(args, pipe, dev, rank, world):
         out = engine.run_sharded_list(names, infer, B, dev)
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (args.backend or "nccl") == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -173,6 +173,10 @@ def main():
         print("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     import torch.distributed as dist
     from rtpe import _native as nat
+    # RTPE_BENCH_SHARE_GPU=1: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
+    # devices; use --backend gloo, RCCL refuses two ranks on one device).  Not a scaling measurement.
+    if os.environ.get("RTPE_BENCH_SHARE_GPU", "0") == "1":
+        local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -251,7 +255,7 @@ def main():
     for k in range(min(args.steps, n_slots)):
         op_ms[:] += np.asarray(eng.read_record(k))
     n_rec = min(args.steps, n_slots)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (args.backend or "nccl") == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -175,12 +175,23 @@ class TeacherPipeline:
         return all_gather_records(rec, equal_counts)
 
 
+def _collective_tensor(t):
+    """RCCL moves device memory; gloo (CPU rehearsals, or several ranks sharing one GPU) wants host memory"""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        return t.cpu(), t.device
+    return t, None
+
+
 def all_gather_records(rec, equal_counts=False):
     """records of all ranks, in rank order.  Variable count per rank: pad to the max, gather,
     strip the padding (one count exchange that the host has to read); with ``equal_counts`` a
     single collective and nothing for the host to wait for."""
     import torch.distributed as dist
     world = dist.get_world_size()
+    rec, home = _collective_tensor(rec)
+    if home is not None:
+        return all_gather_records(rec, equal_counts).to(home)
     if equal_counts:
         out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
         dist.all_gather_into_tensor(out, rec.contiguous())
@@ -330,6 +341,7 @@ def broadcast_state_dict(sd, src=0, device=None):
         if not ks:
             continue
         flat = torch.cat([sd[k].reshape(-1) for k in ks]).to(device)
+        flat, home = _collective_tensor(flat)
         dist.broadcast(flat, src)
         o = 0
         for k in ks:

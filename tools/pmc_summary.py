@@ -30,7 +30,7 @@ def short(name):
     return name.split("(")[0][:80]
 
 
-def load(path, keep_forwards=6, drop_last=3):
+def load(path, keep_forwards=6, drop_last=3, raw_out=None):
     """{(kernel, grid): {counter: [values per dispatch]}} over the timed forwards"""
     rows = list(csv.DictReader(open(path)))
     per_disp = collections.OrderedDict()
@@ -47,8 +47,25 @@ def load(path, keep_forwards=6, drop_last=3):
         b = stems[-drop_last] if drop_last else len(disp)
         disp = disp[a:b]
     out = collections.OrderedDict()
+    nth = 0
     for d in disp:
-        o = out.setdefault((d["name"], d["grid"]), collections.defaultdict(list))
+        if d["name"].startswith("stem_kernel"):
+            nth = 0
+        cls = d["grid"]
+        if d["name"].startswith("conv_block"):
+            # the fused BasicBlock kernel launches one workgroup per CU whatever the map size: the launch classes
+            # are told apart by their place in the forward (32 blocks at 160x160, then 4 at 320x320 for 640x640 inputs)
+            cls = "160x160" if nth < 32 else "320x320"
+            nth += 1
+        d["cls"] = cls
+    if raw_out:
+        with open(raw_out, "w") as f:
+            f.write("kernel,class,grid,workgroup,start_ns,end_ns,counter,value\n")
+            for d in disp:
+                for k, v in d["c"].items():
+                    f.write("%s,%s,%d,%d,%d,%d,%s,%.1f\n" % (d["name"].replace(",", ";"), d["cls"], d["grid"], d["wg"], d["t0"], d["t1"], k, v))
+    for d in disp:
+        o = out.setdefault((d["name"], d["cls"]), collections.defaultdict(list))
         for k, v in d["c"].items():
             o[k].append(v)
         o["_us"].append((d["t1"] - d["t0"]) / 1e3)
@@ -58,8 +75,11 @@ def load(path, keep_forwards=6, drop_last=3):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     merged = collections.OrderedDict()
+    raw_dir = os.path.join(os.path.dirname(dst), os.path.basename(dst).replace("_pmc_summary.json", "_pmc_raw"))
+    os.makedirs(raw_dir, exist_ok=True)
     for path in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
-        for key, cs in load(path).items():
+        pass_name = os.path.relpath(path, src).split(os.sep)[0]
+        for key, cs in load(path, raw_out=os.path.join(raw_dir, pass_name + "_timed_forwards.csv")).items():
             m = merged.setdefault(key, {})
             for k, v in cs.items():
                 if k == "_us":
@@ -73,6 +93,8 @@ def main():
     for (name, grid), c in sorted(merged.items(), key=lambda kv: -sum(kv[1].get("_us_profiled", [0]))):
         n = len(c.get("FETCH_SIZE", c.get("_us_profiled", [])))
         e = {"grid": grid, "launches_per_pass": n}
+        if isinstance(grid, str):
+            e["grid"] = 114688
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             e["fetch_bytes"] = mean(c["FETCH_SIZE"]) * 1024 * 2
             e["write_bytes"] = mean(c["WRITE_SIZE"]) * 1024
@@ -96,10 +118,10 @@ def main():
             tot = mean(c["SQ_WAIT_ANY"]) + mean(c["SQ_ACTIVE_INST_ANY"]) + mean(c.get("SQ_WAIT_INST_ANY", [0]))
             e["wait_any_frac"] = mean(c["SQ_WAIT_ANY"]) / tot if tot else None
         e["us_under_profiler"] = mean(c.get("_us_profiled", []))
-        kernels.setdefault(name, {"classes": {}})["classes"]["grid%d" % grid] = e
+        kernels.setdefault(name, {"classes": {}})["classes"][grid if isinstance(grid, str) else "grid%d" % grid] = e
         f = lambda v, s=1.0, p="%.1f": (p % (v * s)) if v is not None else "-"
         print("%-44s %9d %6s %9s %10s %10s %8s %8s %8s %8s" % (
-            ("%s [%d]" % (name, grid))[:44], n, f(e["us_under_profiler"]), f(e.get("hbm_bytes_per_launch"), 1e-6),
+            ("%s [%s]" % (name, grid))[:44], n, f(e["us_under_profiler"]), f(e.get("hbm_bytes_per_launch"), 1e-6),
             f(e.get("fetch_bytes"), 1e-6), f(e.get("write_bytes"), 1e-6), f(e.get("mfma_util"), 100.0),
             f(e.get("lds_bank_conflict_frac"), 1.0, "%.4f"), f(e.get("valu_mfma_coexec_frac"), 1.0, "%.3f"),
             f(e.get("wait_any_frac"), 1.0, "%.3f")))
@@ -109,11 +131,6 @@ def main():
     except (OSError, ValueError, IndexError):
         pass
     cfg = bench.get("config", {})
-    # name the launch classes of the fused BasicBlock kernel by map size (the larger HBM traffic = 320x320)
-    for name, k in kernels.items():
-        if name.startswith("conv_block") and len(k["classes"]) == 2:
-            a, b = sorted(k["classes"].items(), key=lambda kv: kv[1].get("hbm_bytes_per_launch") or kv[1]["us_under_profiler"])
-            k["classes"] = {"160x160": a[1], "320x320": b[1]}
     out = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 "
                       "(one pass per group: fetch, write, mfma, lds; tools/pmc_passes.sh)",
            "batch": cfg.get("batch_per_gpu"), "size": 640, "unprofiled_bench": {k: bench.get(k) for k in ("value", "ms_per_step")},
