@@ -708,6 +708,501 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Producer / consumer variant ("pc").  Counters of the variants above (profiles/r02_pmc_summary.json): the matrix
+// pipe is busy 42 % of the kernel and SQ_VALU_MFMA_COEXEC is ~0.7 %: the two epilogues (BN / ReLU / transposition
+// / stores, ~45 % of a unit) never run beside matrix work, because the four MFMA waves move through the phases
+// together.  Here the workgroup has EIGHT waves, two per SIMD, whose phases are complementary:
+//   * producers P0-3, interval i: conv1 of unit i (x tile -> accumulators), then its epilogue (BN1 + ReLU -> mid);
+//   * consumers C0-3, interval i: request the x tile of unit i+1 (LDS-DMA; there are no loader waves), epilogue of
+//     unit i-2 (BN2, transposition, + x, ReLU, stores) - VALU / LDS / memory work while the producers' MFMAs own
+//     the matrix pipe - then conv2 of unit i-1 while the producers are in THEIR epilogue.
+// ONE workgroup barrier per unit.  What makes it fit the 160 KiB of LDS: 8 x 16 output tiles (conv1 region
+// 10 x 18 = 180 pixels = 11.25 MFMA column tiles: 3 per producer wave, 94 % useful), and conv2's weight fragments
+// live in the consumer waves' REGISTERS for the whole kernel (14 k-steps x 3 row tiles x 4 VGPRs = 168 of 256) -
+// only conv1's 42 KiB sit in LDS:
+//   W1 42 KiB | x tile (12 rows x 2,240 B) x 2 = 52.5 KiB | mid tile (10 x 18 px) x 2 = 33.75 KiB | output slabs 14 KiB
+// x-tile rows have a 2,240 B pitch (20 pixels = 1,920 B + padding): every tile request is two full-wave LDS-DMA
+// instructions per row with no lane masked off (the 8 spare lanes fetch out-of-range -> zeros into the padding),
+// so the request is straight-line code and the compiler's own s_waitcnt bookkeeping stays exact.
+// Buffers alternate by unit parity: in interval i the producers read X[i&1] and write MID[i&1], the consumers
+// read MID[(i-1)&1] and refill X[(i+1)&1], whose last reader (conv1 of unit i-1) finished before the barrier.
+// The residual is NOT taken from the x tile (it would have to be held for two intervals): each consumer wave
+// re-requests its 3 x 16 B per lane from global memory (an L2 hit: the tile was fetched by the same XCD shortly
+// before) by LDS-DMA into a 3 KiB slab of its own one interval ahead - no registers, no exposed latency.
+// Same k order, same rounding points: bit-identical to the other variants.  Shapes: H % 8 == 0 and W % 16 == 0
+// (every tile complete: the consumers' store count per unit is then a constant, which the counted wait on the
+// DMA relies on); other shapes run the resident-weights variant.
+namespace {
+constexpr int kPTH = 8, kPTW = 16;                    // output tile
+constexpr int kPMH = kPTH + 2, kPMW = kPTW + 2;       // conv1 region = mid tile (10 x 18 = 180 px)
+constexpr int kPXH = kPTH + 4, kPXW = kPTW + 4;       // x tile (12 x 20)
+constexpr int kPNT1 = 3, kPNT2 = 2;                   // 16-pixel tiles per producer / consumer wave
+constexpr int kPXRow = 2240;                          // LDS bytes per x-tile row: >= 2,048 (two full-wave requests) and
+                                                      // == 18 px * 96 B (mod 256): a 16-pixel MFMA column tile that wraps to the
+                                                      // next mid row keeps the conflict-free bank pattern of consecutive pixels
+constexpr int kPMRow = kPMW * kPS;                    // 1,728
+constexpr int kPXBytes = kPXH * kPXRow;               // 26,880
+constexpr int kPMidBytes = kPMH * kPMRow;             // 17,280
+constexpr int kPObuf = kPNT2 * 16 * kRowB;            // 3,584 per consumer wave
+constexpr int kPOffX = 2 * kWSlot;
+constexpr int kPOffMid = kPOffX + 2 * kPXBytes;
+constexpr int kPOffObuf = kPOffMid + 2 * kPMidBytes;
+constexpr int kPOffBn = kPOffObuf + 4 * kPObuf;
+constexpr int kPOffRes = kPOffBn + 96 * 4;            // residual pieces: 3 KiB per consumer wave
+constexpr int kLdsPC = kPOffRes + 4 * 3072;           // 158,336
+constexpr int kPNIT = kPNT2 * 16 * 6 / 64;            // 3 pieces of 16 bytes per consumer lane
+#ifdef RTPE_PC_PRIO
+constexpr int kPrioVector = RTPE_PC_PRIO;
+#else
+constexpr int kPrioVector = 2;
+#endif
+static_assert(kPXW * 6 <= 128 && kPXRow >= 128 * 16, "an x-tile row is two full-wave requests");
+static_assert(kPMH * kPMW <= 4 * kPNT1 * 16, "conv1 region fits the producers' column tiles");
+}
+
+#ifdef RTPE_DIAG
+// diagnostic build only: shader-clock stamps of one workgroup's waves (kept in spare LDS, copied out at the end)
+__device__ unsigned long long g_pc_trace[8 * 64];
+#define RTPE_PC_TRACE(slot)                                                                                     \
+  do {                                                                                                          \
+    if (trace_on && (slot) < 64) {                                                                              \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                             \
+      if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(smem + kLdsPC + (wv * 64 + (slot)) * 8) = t_; \
+    }                                                                                                           \
+  } while (0)
+#define RTPE_PC_TRACE_FLUSH()                                                                                   \
+  do {                                                                                                          \
+    if (trace_on) g_pc_trace[wv * 64 + lane] = *reinterpret_cast<unsigned long long*>(smem + kLdsPC + (wv * 64 + lane) * 8); \
+  } while (0)
+#else
+#define RTPE_PC_TRACE(slot) do { } while (0)
+#define RTPE_PC_TRACE_FLUSH() do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int n_tiles = a.N * a.tiles_x * a.tiles_y;
+  const int G = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd;
+  const int tiles_xcd = min(per_xcd, n_tiles - t_begin);
+  const int U = jw < tiles_xcd ? (tiles_xcd - jw + G - 1) / G : 0;
+  if (U == 0) return;
+  // Wave priorities: a dense MFMA stream (conv2: operands in registers) starves the partner wave's VALU / LDS /
+  // address work on the same SIMD although an MFMA holds the vector issue for only half of its cycles - measured
+  // (tools/pc_trace.py): the producers' epilogue ran 3x slower beside conv2 than alone.  So everything that is not
+  // a k loop runs at raised priority and takes the issue slots it needs; the k loop fills the rest.
+  __builtin_amdgcn_s_setprio(kPrioVector);
+#ifdef RTPE_DIAG
+  const bool trace_on = blockIdx.x == 8 * 3 + 2 && a.H == 160;   // one workgroup in the middle of XCD 2
+  if (trace_on) *reinterpret_cast<unsigned long long*>(smem + kLdsPC + tid * 8) = 0ull;
+#endif
+  const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
+  auto unit_origin = [&](int u, uint32_t* n, int* py0, int* px0) __attribute__((always_inline)) {
+    uint32_t t = (uint32_t)(t_begin + jw + u * G);
+    *n = fdiv(t, a.div_tiles_xy);
+    t -= *n * tiles_xy;
+    const uint32_t tyi = fdiv(t, a.div_tiles_x);
+    *py0 = (int)tyi * kPTH;
+    *px0 = (int)(t - tyi * a.tiles_x) * kPTW;
+  };
+  const int r = lane & 15, g = lane >> 4;
+  const int hi = g >= 2 ? 1 : 0;
+  // byte offset of k-step k (32 input channels from channel 32k % 48 of tap 32k / 48) in a tile of row pitch rowb
+  auto koff = [](int k, int rowb) constexpr { const int tap = (32 * k) / 48; return (tap / 3) * rowb + (tap % 3) * kPS + ((32 * k) % 48) * 2; };
+
+  // x-tile request: wave quarter wq (= wave & 3) asks for rows [3 wq, 3 wq + 3) of the tile of unit u into buffer
+  // `par`: 6 full-wave LDS-DMA instructions, no branches.  Per-lane constants (column, 16-byte slot) are kept.
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, a.x_bytes, 0x00020000);
+  const int wq = wv & 3;
+  int xcol[2];
+  uint32_t xoffs[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = k * 64 + lane;
+    const int hx = q / 6, sl = q - hx * 6;
+    xcol[k] = q < kPXW * 6 ? hx - 2 : -(1 << 20);          // column relative to the tile's first output column
+    xoffs[k] = (uint32_t)((hx - 2) * a.in_ld + sl * 8) * 2u;
+  }
+  // in two halves, so that the address arithmetic can be done while waiting at the barrier
+  struct XReq { uint32_t voff[2][kPXH / 4]; int soff[kPXH / 4]; };
+  auto prepare_x = [&](int u, XReq& q) __attribute__((always_inline)) {
+    uint32_t n;
+    int py0, px0;
+    unit_origin(u, &n, &py0, &px0);
+    const int iy0 = py0 - 2 + wq * (kPXH / 4);
+    uint32_t voff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      voff[k] = (unsigned)(px0 + xcol[k]) < (unsigned)a.W ? xoffs[k] + (uint32_t)(px0 * a.in_ld) * 2u : 0x80000000u;
+    const int img_row0 = (int)n * a.H;
+#pragma unroll
+    for (int j = 0; j < kPXH / 4; ++j) {
+      const int iy = iy0 + j;
+      const bool row_ok = (unsigned)iy < (unsigned)a.H;
+      q.soff[j] = row_ok ? (img_row0 + iy) * a.W * a.in_ld * 2 : 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) q.voff[k][j] = row_ok ? voff[k] : 0x80000000u;
+    }
+  };
+  auto fire_x = [&](const XReq& q, int par) __attribute__((always_inline)) {
+    char* buf = smem + kPOffX + par * kPXBytes + wq * (kPXH / 4) * kPXRow;
+#pragma unroll
+    for (int j = 0; j < kPXH / 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(buf + j * kPXRow + k * 1024), 16, (int)q.voff[k][j],
+                                                 q.soff[j], 0, 0);
+  };
+  auto issue_x = [&](int u, int par) __attribute__((always_inline)) {
+    XReq q;
+    prepare_x(u, q);
+    fire_x(q, par);
+  };
+
+  if (wv < 4) {
+    // =========================== producers: conv1 + BN1 + ReLU -> mid tile ===========================
+    int ba[kPNT1], bb[kPNT1], bc[kPNT1];
+#pragma unroll
+    for (int nt = 0; nt < kPNT1; ++nt) {
+      int p = (wv * kPNT1 + nt) * 16 + r;
+      p = p < kPMH * kPMW ? p : kPMH * kPMW - 1;           // the 12 idle columns of the last tile recompute a pixel
+      const int my = p / kPMW, mx = p - my * kPMW;
+      ba[nt] = kPOffX + my * kPXRow + mx * kPS + g * 16;
+      bb[nt] = ba[nt] + hi * (kPXRow - 3 * kPS);           // k-step 4: lanes 32-63 are in tap (1,0), not "(0,3)"
+      bc[nt] = ba[nt] - hi * (2 * kPXRow + 2 * kPS + 96);  // k-step 13: lanes 32-63 = zero-weight padding, tap (0,0)
+    }
+    // epilogue: accumulator column r of tile nt is mid pixel p (the idle columns of the last tile recompute
+    // pixel 179 and store the same bits to the same place); this lane's 4 channels start at g * 4
+    int moff[kPNT1], myx[kPNT1];
+#pragma unroll
+    for (int nt = 0; nt < kPNT1; ++nt) {
+      int p = (wv * kPNT1 + nt) * 16 + r;
+      p = p < kPMH * kPMW ? p : kPMH * kPMW - 1;
+      moff[nt] = p * kPS + g * 8;
+      myx[nt] = ((p / kPMW) << 8) | (p % kPMW);
+    }
+    float4v al1[kMT], be1[kMT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+      const int c4 = m * 16 + g * 4;
+      al1[m] = *reinterpret_cast<const float4v*>(a.ab1 + c4);
+      be1[m] = *reinterpret_cast<const float4v*>(a.ab1 + 48 + c4);
+    }
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) asm volatile("" : "+v"(al1[m]), "+v"(be1[m]));
+    const char* wl = smem + lane * 16;                     // conv1's fragments, resident
+    for (int i = 0; i < U; ++i) {
+      uint32_t n;
+      int py0, px0;
+      unit_origin(i, &n, &py0, &px0);
+      const int xsel = (i & 1) * kPXBytes;
+      // the tile of unit i+1 goes into the buffer conv1 of unit i-1 releases at the barrier (the last interval
+      // re-requests the last tile: nobody reads it); addresses first, the requests right after the barrier
+      XReq xq;
+      prepare_x(i + 1 < U ? i + 1 : U - 1, xq);
+#pragma unroll
+      for (int j = 0; j < kPXH / 4; ++j) asm volatile("" : "+v"(xq.voff[0][j]), "+v"(xq.voff[1][j]), "+s"(xq.soff[j]));
+      RTPE_PC_TRACE(i * 5 + 0);
+      RTPE_BBARRIER();                                     // B(i): x tile i landed, MID[i&1] free
+      RTPE_PC_TRACE(i * 5 + 1);
+      RTPE_PC_TRACE(i * 5 + 2);
+      float4v acc[kMT][kPNT1];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < kPNT1; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+      if (!(a.ablate & 4)) {
+        const char* ta[kPNT1];
+        const char* tb[kPNT1];
+        const char* tc[kPNT1];
+#pragma unroll
+        for (int nt = 0; nt < kPNT1; ++nt) {
+          ta[nt] = smem + ba[nt] + xsel; tb[nt] = smem + bb[nt] + xsel; tc[nt] = smem + bc[nt] + xsel;
+        }
+        auto bptr = [&](int k, int nt) __attribute__((always_inline)) {
+          return reinterpret_cast<const half8*>((k == 4 ? tb[nt] : k == 13 ? tc[nt] : ta[nt]) + koff(k, kPXRow));
+        };
+        // operands are fetched TWO k-steps ahead (three register sets): with 3 x 3 MFMAs per k-step (144 cycles)
+        // and the four producer waves reading in step, a fetch issued one step ahead is not back in time
+        half8 af[3][kMT], bf[3][kPNT1];
+        __builtin_amdgcn_s_setprio(0);                     // see kPrioVector
+#pragma unroll
+        for (int s0 = 0; s0 < 2; ++s0) {
+#pragma unroll
+          for (int m = 0; m < kMT; ++m) af[s0][m] = *reinterpret_cast<const half8*>(wl + (s0 * kMT + m) * 1024);
+#pragma unroll
+          for (int nt = 0; nt < kPNT1; ++nt) bf[s0][nt] = *bptr(s0, nt);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2 * kKH; ++kk) {
+          const int cur = kk % 3, nxt = (kk + 2) % 3;
+          if (kk + 2 < 2 * kKH) {
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) af[nxt][m] = *reinterpret_cast<const half8*>(wl + ((kk + 2) * kMT + m) * 1024);
+#pragma unroll
+            for (int nt = 0; nt < kPNT1; ++nt) bf[nxt][nt] = *bptr(kk + 2, nt);
+          }
+#pragma unroll
+          for (int m = 0; m < kMT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < kPNT1; ++nt)
+              acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][m], bf[cur][nt], acc[m][nt], 0, 0, 0);
+          if (kk + 2 < 2 * kKH) {
+#pragma unroll
+            for (int q = 0; q < kMT + kPNT1; ++q) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(kPrioVector);
+      }
+#ifdef RTPE_DIAG
+      if (!(a.ablate & 32))
+#endif
+      fire_x(xq, (i + 1) & 1);                             // after the k loop: requests in flight slow its LDS reads by ~15 %
+      RTPE_PC_TRACE(i * 5 + 3);
+      // ---- BN1 + ReLU -> fp16 rows of MID[i&1] (zeros outside the image = conv2's padding) ----
+      if (!(a.ablate & 1)) {
+        char* mid = smem + kPOffMid + (i & 1) * kPMidBytes;
+        // a tile whose 10 x 18 conv1 region lies inside the image (all but the border tiles) needs no masking
+        const bool interior = py0 >= 1 && py0 + kPTH < a.H && px0 >= 1 && px0 + kPTW < a.W;
+        auto bn_relu = [&](int m, int nt) __attribute__((always_inline)) {
+          const float4v v = acc[m][nt];
+          float2v lo{v[0], v[1]}, hi2{v[2], v[3]};
+          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+          hi2 = __builtin_convertvector(__builtin_convertvector(hi2, half2v), float2v);
+          lo = __builtin_elementwise_fma(lo, float2v{al1[m][0], al1[m][1]}, float2v{be1[m][0], be1[m][1]});
+          hi2 = __builtin_elementwise_fma(hi2, float2v{al1[m][2], al1[m][3]}, float2v{be1[m][2], be1[m][3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi2, half2v);
+          half4 o{olo[0], olo[1], ohi[0], ohi[1]};
+          short4v b = __builtin_bit_cast(short4v, o);
+          return b & ~(b >> 15);
+        };
+        if (interior) {
+#pragma unroll
+          for (int nt = 0; nt < kPNT1; ++nt)
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) *reinterpret_cast<short4v*>(mid + moff[nt] + m * 32) = bn_relu(m, nt);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < kPNT1; ++nt) {
+            const int iy = py0 - 1 + (myx[nt] >> 8), ix = px0 - 1 + (myx[nt] & 255);
+            const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) {
+              short4v b = bn_relu(m, nt);
+              if (!inside) b = b ^ b;
+              *reinterpret_cast<short4v*>(mid + moff[nt] + m * 32) = b;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      RTPE_PC_TRACE(i * 5 + 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's rows of tile i+1 have landed
+    }
+    RTPE_PC_TRACE(U * 5 < 60 ? U * 5 : 60);
+    RTPE_BBARRIER();                                       // B(U): the consumers' last conv2
+    RTPE_PC_TRACE_FLUSH();
+    return;
+  }
+
+  // ========== consumers: x-tile requests; BN2 + x + ReLU + stores of unit i-2; conv2 (weights in registers) of unit i-1 ==========
+  const int cw = wv - 4;                                   // output rows 2 cw, 2 cw + 1 of the tile
+  // prologue: conv1's weights into LDS (a quarter per consumer wave), BN2 parameters, x tiles 0 and 1
+  {
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w1), 0, 2 * kWSlot, 0x00020000);
+    const int voff = lane * 16;
+    for (int p = cw; p < 2 * kMT * kKH; p += 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(smem + p * 1024), 16, voff, p * 1024, 0, 0);
+    if (cw == 0 && lane < 24) reinterpret_cast<float4*>(smem + kPOffBn)[lane] = reinterpret_cast<const float4*>(a.ab2)[lane];
+  }
+  issue_x(0, 0);
+  // conv2's weight fragments: this lane's 16 bytes of every (k-step, row tile), kept for the whole kernel
+  half8 w2[2 * kKH][kMT];
+#pragma unroll
+  for (int k = 0; k < 2 * kKH; ++k)
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+      w2[k][m] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(a.w2) + ((k * kMT + m) * 64 + lane) * 16);
+  int ca[kPNT2];
+#pragma unroll
+  for (int nt = 0; nt < kPNT2; ++nt)
+    ca[nt] = kPOffMid + ((cw * kPNT2 + nt) * kPMW + r) * kPS + g * 16;   // output pixel (row 2 cw + nt, column r)
+  // k-steps 4 and 13: lanes 32-63 are in tap (1,0) / in the zero-weight padding (see the producers' bb, bc)
+  const int hi4 = hi * (kPMRow - 3 * kPS), hi13 = -hi * (2 * kPMRow + 2 * kPS + 96);
+  // 16-byte pieces of this wave's two output rows: piece c = it * 64 + lane -> slab pixel c / 6 (row c / 96 of
+  // the pair, column (c / 6) % 16), slot c % 6.  Offsets in the slab, in x and in y (bytes from the pair's first pixel)
+  uint32_t ooffs[kPNIT], yoffr[kPNIT];
+#pragma unroll
+  for (int it = 0; it < kPNIT; ++it) {
+    const int c = it * 64 + lane;
+    const int pw = c / 6, slot = c - pw * 6;
+    ooffs[it] = (uint32_t)(pw * kRowB + slot * 16);
+    yoffr[it] = (uint32_t)(((pw >> 4) * a.W + (pw & 15)) * a.out_ld * 2 + slot * 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // W1, BN2, both x tiles, w2 registers
+  // tell the compiler too: otherwise it keeps the 42 loads "pending" at the loop header and counts them down
+  // with s_waitcnt vmcnt(N) inside the k loop - N so small for the last ones that the wait would also cover the
+  // x-tile requests issued a moment earlier
+#pragma unroll
+  for (int k = 0; k < 2 * kKH; ++k)
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) asm volatile("" : "+v"(w2[k][m]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  float4v acc[kMT][kPNT2];
+  auto conv2 = [&](int v) __attribute__((always_inline)) {
+    const int msel = (v & 1) * kPMidBytes;
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kPNT2; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    if (a.ablate & 8) return;
+    const char* ta[kPNT2];
+#pragma unroll
+    for (int nt = 0; nt < kPNT2; ++nt) ta[nt] = smem + ca[nt] + msel;
+    auto bptr = [&](int k, int nt) __attribute__((always_inline)) {
+      return reinterpret_cast<const half8*>(ta[nt] + (k == 4 ? hi4 : k == 13 ? hi13 : 0) + koff(k, kPMRow));
+    };
+    half8 bf[3][kPNT2];                                    // fetched two k-steps ahead, as in conv1
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int s0 = 0; s0 < 2; ++s0)
+#pragma unroll
+      for (int nt = 0; nt < kPNT2; ++nt) bf[s0][nt] = *bptr(s0, nt);
+#pragma unroll
+    for (int kk = 0; kk < 2 * kKH; ++kk) {
+      const int cur = kk % 3, nxt = (kk + 2) % 3;
+      if (kk + 2 < 2 * kKH) {
+#pragma unroll
+        for (int nt = 0; nt < kPNT2; ++nt) bf[nxt][nt] = *bptr(kk + 2, nt);
+      }
+#pragma unroll
+      for (int m = 0; m < kMT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < kPNT2; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[kk][m], bf[cur][nt], acc[m][nt], 0, 0, 0);
+      if (kk + 2 < 2 * kKH) {
+#pragma unroll
+        for (int q = 0; q < kPNT2; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(kPrioVector);
+  };
+  // BN2 parameters of this lane's channels (m * 16 + g * 4 ... + 3): fetched from LDS one interval ahead
+  struct Bn2 { float4v al[kMT], be[kMT]; };
+  auto load_bn = [&](Bn2& bn) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+      bn.al[m] = *reinterpret_cast<const float4v*>(smem + kPOffBn + (m * 16 + g * 4) * 4);
+      bn.be[m] = *reinterpret_cast<const float4v*>(smem + kPOffBn + (48 + m * 16 + g * 4) * 4);
+    }
+  };
+  // residual request for unit v: this wave's 192 pieces (3 full-wave LDS-DMA instructions) into its slab, piece
+  // it * 64 + lane at it * 1024 + lane * 16; returns the address of the pair's first output pixel
+  char* const res = smem + kPOffRes + cw * 3072;
+  auto request_residual = [&](int v) __attribute__((always_inline)) -> char* {
+    uint32_t n;
+    int py0, px0;
+    unit_origin(v, &n, &py0, &px0);
+    const int pix0 = ((int)n * a.H + py0 + cw * kPNT2) * a.W + px0;
+    int lane_r = lane;
+    asm volatile("" : "+v"(lane_r));                       // offsets recomputed per unit: no registers held
+#pragma unroll
+    for (int it = 0; it < kPNIT; ++it) {
+      const int c = it * 64 + lane_r;
+      const int pw = c / 6, slot = c - pw * 6;
+      const int voff = ((pw >> 4) * a.W + (pw & 15)) * a.in_ld * 2 + slot * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(res + it * 1024), 16, voff, pix0 * a.in_ld * 2, 0, 0);
+    }
+    return reinterpret_cast<char*>(a.y + (size_t)pix0 * a.out_ld);
+  };
+  // BN2 of the accumulators, transposed through this wave's slab, + x, ReLU, store
+  auto epilogue = [&](const Bn2& bn, char* yb) __attribute__((always_inline)) {
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int re = lane_e & 15, ge = lane_e >> 4;
+    char* obuf = smem + kPOffObuf + cw * kPObuf;
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+      const float4v al = bn.al[m], be = bn.be[m];
+#pragma unroll
+      for (int nt = 0; nt < kPNT2; ++nt) {
+        const float4v vv = acc[m][nt];
+        float2v lo{vv[0], vv[1]}, hi2{vv[2], vv[3]};
+        lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
+        hi2 = __builtin_convertvector(__builtin_convertvector(hi2, half2v), float2v);
+        lo = __builtin_elementwise_fma(lo, float2v{al[0], al[1]}, float2v{be[0], be[1]});
+        hi2 = __builtin_elementwise_fma(hi2, float2v{al[2], al[3]}, float2v{be[2], be[3]});
+        const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi2, half2v);
+        *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the residual pieces have landed (requested an interval ago)
+#pragma unroll
+    for (int it = 0; it < kPNIT; ++it) {
+      const half8 ov = *reinterpret_cast<const half8*>(obuf + ooffs[it]);
+      const half8 rv = *reinterpret_cast<const half8*>(res + it * 1024 + lane_e * 16);
+      half8 o = ov + rv;                                   // fp16 add, round-to-nearest-even = the wrapper's add
+      short8 b = __builtin_bit_cast(short8, o);
+      b = b & ~(b >> 15);
+      *reinterpret_cast<short8*>(yb + yoffr[it]) = b;      // every tile is complete
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slab is read: the next request may overwrite it
+  };
+
+  RTPE_BBARRIER();                                         // B(0)
+  Bn2 bn;
+  char* yb_next = nullptr;
+  // interval 1: conv2 of unit 0 only (no finished unit yet)
+  if (U > 1) {
+    RTPE_BBARRIER();                                       // B(1): MID[0] complete
+    yb_next = request_residual(0);
+    conv2(0);
+    load_bn(bn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  for (int i = 2; i <= U; ++i) {
+    RTPE_PC_TRACE((i - 2) * 5 + 0);
+    RTPE_BBARRIER();                                       // B(i): MID[(i-1)&1] complete
+    RTPE_PC_TRACE((i - 2) * 5 + 1);
+    char* const yb = yb_next;
+    epilogue(bn, yb);                                      // unit i-2
+    RTPE_PC_TRACE((i - 2) * 5 + 2);
+    yb_next = request_residual(i - 1);
+    RTPE_PC_TRACE((i - 2) * 5 + 3);
+    conv2(i - 1);
+    RTPE_PC_TRACE((i - 2) * 5 + 4);
+    load_bn(bn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  {
+    // the last unit (U == 1: its conv2 has not run yet - MID[0] is complete after B(1))
+    if (U == 1) {
+      RTPE_BBARRIER();                                     // B(1)
+      yb_next = request_residual(0);
+      conv2(0);
+      load_bn(bn);
+    }
+    epilogue(bn, yb_next);
+  }
+  RTPE_PC_TRACE_FLUSH();
+}
+
+
 bool conv_block_supports(int cin, int cout, int H, int W) { return cin == 48 && cout == 48 && H >= kTH && W >= 16; }
 
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,
@@ -719,19 +1214,24 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   // option "block_ring" (or RTPE_BLOCK_RING=1): the variant that streams the weights through a 3-slot ring
   // (bit-identical results; kept for A/B measurements in one process)
   const int ring = get_option(kOptBlockRing);
+  // option "block_pc" (default 1; RTPE_BLOCK_PC=0 or rtpe_set_option("block_pc", 0) to disable): the producer /
+  // consumer variant wherever the shape allows it (complete 8 x 16 tiles); bit-identical results
+  const bool pc = get_option(kOptBlockPC) != 0 && !ring && H % kPTH == 0 && W % kPTW == 0;
   static unsigned long long attr_mask = 0;
   if (first_use_on_device(&attr_mask)) {
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_rw_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block_pc_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   BlockArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.ab1 = ab1; a.ab2 = ab2;
   a.N = N; a.H = H; a.W = W; a.in_ld = in_ld; a.out_ld = out_ld;
-  a.tiles_x = (W + kTW - 1) / kTW;
-  a.tiles_y = (H + kTH - 1) / kTH;
+  a.tiles_x = pc ? W / kPTW : (W + kTW - 1) / kTW;
+  a.tiles_y = pc ? H / kPTH : (H + kTH - 1) / kTH;
   a.div_tiles_x = make_fastdiv(a.tiles_x);
   a.div_tiles_xy = make_fastdiv(a.tiles_x * a.tiles_y);
   a.x_bytes = (int)x_bytes;
@@ -740,7 +1240,13 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
   long G = 32;                                            // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
-  if (ring)
+  if (pc)
+#ifdef RTPE_DIAG
+    hipLaunchKernelGGL(conv_block_pc_kernel, dim3((unsigned)(8 * G)), dim3(512), kLdsPC + 8 * 64 * 8, s, a);
+#else
+    hipLaunchKernelGGL(conv_block_pc_kernel, dim3((unsigned)(8 * G)), dim3(512), kLdsPC, s, a);
+#endif
+  else if (ring)
     hipLaunchKernelGGL(conv_block_kernel, dim3((unsigned)(8 * G)), dim3((kWaves + kLoad) * 64), kLds, s, a);
   else
     hipLaunchKernelGGL(conv_block_rw_kernel, dim3((unsigned)(8 * G)), dim3((kWaves + kLoad) * 64), kLdsRW, s, a);
@@ -749,3 +1255,9 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
 }
 
 }  // namespace rtpe
+
+#ifdef RTPE_DIAG
+extern "C" int rtpe_diag_pc_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rtpe::g_pc_trace), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -63,12 +63,13 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "", "", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "", "", ""};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "", ""};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
-    v = kOptionEnv[key][0] ? env_int(kOptionEnv[key], 0) : 0;
+    v = kOptionEnv[key][0] ? env_int(kOptionEnv[key], kOptionDefault[key]) : kOptionDefault[key];
     __atomic_store_n(&g_options[key], v, __ATOMIC_RELAXED);
   }
   return v;

@@ -1099,7 +1099,8 @@ def test_teacher_prediction_export_and_reader(nat, teacher, tmp_path):
 # --------------------------------------------------------------------------- #
 # fused BasicBlock (conv_block.hip)
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("case", [(2, 32, 48), (1, 23, 37), (8, 160, 160), (3, 6, 16), (5, 70, 100)],
+@pytest.mark.parametrize("case", [(2, 32, 48), (1, 23, 37), (8, 160, 160), (3, 6, 16), (5, 70, 100), (3, 8, 32), (2, 16, 64), (12, 64, 128),
+                                  (17, 32, 96)],
                          ids=lambda c: "block_n%d_%dx%d" % c)
 def test_fused_basicblock_equals_two_convs(nat, case):
     """the fused kernel must be BIT-identical to conv+BN+ReLU followed by conv+BN+add+ReLU (same k order,
@@ -1123,8 +1124,10 @@ def test_fused_basicblock_equals_two_convs(nat, case):
     nat.check(L.rtpe_conv2d_nhwc(mid.data_ptr(), N, H, W, 48, ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
                                  be[1].ctypes.data_as(fpt), 48, 3, 1, nat.F_RELU | nat.F_ROUND_CONV, xd.data_ptr(),
                                  ref.data_ptr(), st))
-    # both variants of the fused kernel: weights resident in LDS (default) and streamed through the 3-slot ring
-    for ring in (0, 1):
+    # the variants of the fused kernel: the producer / consumer kernel (default wherever H % 8 == 0 and W % 16 == 0;
+    # other shapes run the resident-weights kernel), weights resident in LDS, weights streamed through the 3-slot ring
+    for variant, (pc, ring) in enumerate(((1, 0), (0, 0), (0, 1))):
+        nat.check(L.rtpe_set_option(b"block_pc", pc))
         nat.check(L.rtpe_set_option(b"block_ring", ring))
         try:
             got = torch.full_like(xd, float("nan"))
@@ -1132,9 +1135,10 @@ def test_fused_basicblock_equals_two_convs(nat, case):
                                              be[0].ctypes.data_as(fpt), ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
                                              be[1].ctypes.data_as(fpt), got.data_ptr(), st))
         finally:
+            nat.check(L.rtpe_set_option(b"block_pc", 1))
             nat.check(L.rtpe_set_option(b"block_ring", 0))
         a, b = got.cpu().view(torch.int16), ref.cpu().view(torch.int16)
-        assert torch.equal(a, b), "ring=%d: %d of %d elements differ" % (ring, (a != b).sum().item(), a.numel())
+        assert torch.equal(a, b), "variant %d: %d of %d elements differ" % (variant, (a != b).sum().item(), a.numel())
 
 
 # --------------------------------------------------------------------------- #

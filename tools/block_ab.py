@@ -1,5 +1,5 @@
 """GPU probe: A/B of kernel variants inside ONE process (interleaved rounds, per-op HIP events of the whole
-forward at batch 32, 640x640): the fused BasicBlock kernel with resident weights vs the weight ring.
+forward at batch 32, 640x640): the fused BasicBlock kernel - resident weights vs weight ring vs producer / consumer.
 
     python tools/block_ab.py [rounds]
 """
@@ -34,18 +34,20 @@ def main():
         if t[7] == -900001:
             ds = eng.program.tensors[eng.program.ops[i].out_t].ds_log2
             blocks.setdefault(ds, []).append(i)
-    res = {0: [], 1: []}
+    res = {0: [], 1: [], 2: []}
     for r in range(rounds):
-        for ring in (0, 1):
-            nat.check(nat.lib().rtpe_set_option(b"block_ring", ring))
+        for ring in (0, 1, 2):
+            nat.check(nat.lib().rtpe_set_option(b"block_ring", int(ring == 1)))
+            nat.check(nat.lib().rtpe_set_option(b"block_pc", int(ring == 2)))
             eng.forward(x)
             _, ms = eng.forward_timed(x)
             ms = np.array(ms)
             res[ring].append((float(ms.sum()), {ds: float(np.mean([ms[i] + ms[i + 1] for i in idx])) for ds, idx in blocks.items()}))
     nat.check(nat.lib().rtpe_set_option(b"block_ring", 0))
-    for ring in (0, 1):
+    nat.check(nat.lib().rtpe_set_option(b"block_pc", 1))
+    for ring in (0, 1, 2):
         tot = [t for t, _ in res[ring]]
-        line = "%-18s forward (events) median %.3f min %.3f ms" % ("weight ring" if ring else "resident weights", np.median(tot), min(tot))
+        line = "%-18s forward (events) median %.3f min %.3f ms" % (("resident weights", "weight ring", "producer/consumer")[ring], np.median(tot), min(tot))
         for ds in sorted(blocks):
             v = [b[ds] for _, b in res[ring]]
             line += " | block @/%d median %.1f min %.1f us" % (1 << ds, np.median(v) * 1e3, min(v) * 1e3)
