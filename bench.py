@@ -303,7 +303,13 @@ def main():
         dom_ms = float(np.mean([op_ms[i] + op_ms[i + 1] for i in heads]))
         dom_bytes = float(np.mean([costs[i][1] + costs[i + 1][1] for i in heads]))
         dom_flops = float(np.mean([costs[i][0] + costs[i + 1][0] for i in heads]))
-        dom_kernel = "conv_block_rw_kernel (fused BasicBlock: conv+BN+ReLU+conv+BN+add+ReLU, weights resident in LDS)"
+        # 160 % 8 == 0 and 160 % 16 == 0: the producer / consumer kernel unless RTPE_BLOCK_PC=0
+        hh = S // 4
+        pc = os.environ.get("RTPE_BLOCK_PC", "1") != "0" and os.environ.get("RTPE_BLOCK_RING", "0") == "0" \
+            and hh % 8 == 0 and hh % 16 == 0
+        dom_kernel = ("conv_block_pc_kernel (fused BasicBlock: conv+BN+ReLU+conv+BN+add+ReLU; 4 producer + 4 consumer waves)"
+                      if pc else
+                      "conv_block_rw_kernel (fused BasicBlock: conv+BN+ReLU+conv+BN+add+ReLU, weights resident in LDS)")
     else:
         dom_launches = len(dom_idx)
         dom_ms = float(np.mean([op_ms[i] for i in dom_idx]))

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int c = kk - tap * a.cc;
     const int tyy = (a.tapw == 3) ? (tap * 11 >> 5) : (a.tapw == 2 ? (tap >> 1) : (a.tapw == 5 ? (tap * 13 >> 6) : 0));
     const int txx = tap - tyy * a.tapw;
-    tapoff[i] = (tyy * a.dil * a.halo_w + txx * a.dil) * a.pstride + c * ES;
+    tapoff[i] = tyy * a.dil * a.rowb + txx * a.dil * a.pstride + c * ES;
   }
 
   // per-lane pixel of each N tile
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const uint32_t p = (wv * NT + nt) * 16 + r;
     const uint32_t oy = fdiv(p, a.div_tw);
     const uint32_t ox = p - oy * a.tw;
-    pixbase[nt] = (int)((oy * a.in_mul * a.halo_w + ox * a.in_mul) * a.pstride);
+    pixbase[nt] = (int)(oy * a.in_mul * a.rowb + ox * a.in_mul * a.pstride);
   }
 
   float4v acc[MT][NT];
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const uint32_t hx = fdiv(q, a.div_slots);
         const uint32_t s = q - hx * slots;
         const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
-        dst[u] = idx < total ? (int)((hy * a.halo_w + hx) * a.pstride + s * 16) : -1;
+        dst[u] = idx < total ? (int)(hy * a.rowb + hx * a.pstride + s * 16) : -1;
         v[u] = make_uint4(0, 0, 0, 0);
         if (idx < total && (unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in &&
             cbase + (int)s * EPS < a.cin)
@@ -441,6 +441,21 @@ void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w_in, v
             }
 }
 
+// ds_read_b128 serves a wave in four groups of 16 lanes over 64 banks of 4 bytes (MI355X guide, LDS section).  The
+// 16 lanes r of a B-operand read are 16 consecutive output pixels: with pstride % 64 == 32 bytes they are
+// conflict-free as long as they lie in one tile row.  When tw is not a multiple of 16 a column tile wraps to the
+// next row, in_mul * rowb - tw * in_mul * pstride bytes further than the next pixel would be: the row pitch is
+// padded until that difference is a multiple of the 256-byte bank period (model: 6.4 -> 4.0 LDS cycles per read
+// for 20-wide tiles, 4.8 -> 4.0 for 40-wide ones).
+int conv_row_pitch(const ConvPlan& p, int tw) {
+  const int hw = (tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
+  int rb = hw * p.pstride;
+  static const int pad = getenv("RTPE_CONV_ROWPAD") ? atoi(getenv("RTPE_CONV_ROWPAD")) : 1;
+  if (pad && p.esize == 2 && tw % 16 != 0)
+    while ((p.in_mul * rb - tw * p.in_mul * p.pstride) % 256 != 0) rb += 16;
+  return rb;
+}
+
 struct TileCand { int waves, nt, th, tw; };
 static const TileCand kCands[] = {
     {4, 8, 16, 32}, {4, 8, 32, 16}, {4, 4, 16, 16}, {4, 4, 8, 32}, {4, 4, 32, 8},
@@ -449,8 +464,8 @@ static const TileCand kCands[] = {
 };
 
 static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
-  const int hh = (th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1, hw = (tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
-  const size_t in_tile = (size_t)hh * hw * p.pstride;
+  const int hh = (th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
+  const size_t in_tile = (size_t)hh * conv_row_pitch(p, tw);
   const size_t out_tile = (size_t)waves * nt * 16 * (p.mt * 16 * p.esize + 16);   // epilogue transpose buffer
   return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
 }
@@ -464,7 +479,7 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != 2 || p.n_cchunks != 1)) return false;
   const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
   if (hw * 6 > 256) return false;                        // a halo row is at most 4 DMA instructions
-  const size_t in_tile = (size_t)hh * hw * p.pstride;
+  const size_t in_tile = (size_t)hh * conv_row_pitch(p, c.tw);
   const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
   size_t buf = in_tile > out_tile ? in_tile : out_tile;
   buf = (buf + 255) / 256 * 256;
@@ -562,6 +577,7 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->dil = p.dil;
   a->halo_h = (t.th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   a->halo_w = (t.tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
+  a->rowb = conv_row_pitch(p, t.tw);
   a->tiles_x = (a->W_pos + t.tw - 1) / t.tw;
   a->tiles_y = (a->H_pos + t.th - 1) / t.th;
   a->div_tw = make_fastdiv(t.tw);
@@ -614,9 +630,6 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                          ((double)H_pos * W_pos);
     if (waste > 1.35 * min_waste) continue;
-    const int hh = (c.th - 1) * p.in_mul + p.tapw, hw = (c.tw - 1) * p.in_mul + p.tapw;
-    const size_t in_tile = (size_t)hh * hw * p.pstride;
-    const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
     ConvTile t;
     memset(&t, 0, sizeof(t));
     t.nt = c.nt; t.waves = c.waves; t.th = c.th; t.tw = c.tw;

@@ -217,7 +217,7 @@ conv_stream_kernel(const ConvArgs a) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const int rowslots = a.halo_w * kSlots;
-    const int rowbytes = a.halo_w * kPStride;
+    const int rowbytes = a.rowb;
     auto issue = [&](int s, int r0, int r1) {           // halo rows [r0, r1) of the tile of stage s
       int tile, cb;
       um.get(s >> sh, &tile, &cb);
@@ -305,7 +305,7 @@ conv_stream_kernel(const ConvArgs a) {
     if (kk >= 9 * kCC) kk -= 9 * kCC;                   // zero-weight k padding: any finite in-tile data
     const int tap = kk / kCC, c = kk - tap * kCC;
     const int ty = tap / 3, tx = tap - ty * 3;
-    toff[k] = (ty * a.halo_w + tx) * kPStride + c * 2;
+    toff[k] = ty * a.rowb + tx * kPStride + c * 2;
   }
   int pixbase[NT];
 #pragma unroll
@@ -313,7 +313,7 @@ conv_stream_kernel(const ConvArgs a) {
     const uint32_t p = (wv * NT + nt) * 16 + r;
     const uint32_t oy = fdiv(p, a.div_tw);
     const uint32_t ox = p - oy * a.tw;
-    pixbase[nt] = (int)((oy * a.in_mul * a.halo_w + ox * a.in_mul) * kPStride);   // in_mul = conv stride
+    pixbase[nt] = (int)(oy * a.in_mul * a.rowb + ox * a.in_mul * kPStride);      // in_mul = conv stride
   }
   constexpr int ROWB = MT * 32 + 16;
   constexpr int CH = MT * 2;
@@ -641,7 +641,7 @@ int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, 
                "streaming conv: LDS layout (%d buffers of %d B, %d weight slots, %zu B)", t.n_bufs, t.buf_bytes,
                t.n_wslots, t.lds_bytes);
   RTPE_REQUIRE(a.halo_w * kSlots <= 256, "streaming conv: halo row of %d pixels", a.halo_w);
-  RTPE_REQUIRE((size_t)a.halo_h * a.halo_w * kPStride <= (size_t)t.buf_bytes &&
+  RTPE_REQUIRE(a.rowb >= a.halo_w * kPStride && (size_t)a.halo_h * a.rowb <= (size_t)t.buf_bytes &&
                (size_t)t.waves * t.nt * 16 * (p.mt * 32 + 16) <= (size_t)t.buf_bytes, "streaming conv: tile buffer too small");
 #define RTPE_S(MTv, NTv, Wv) \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_stream<MTv, NTv, Wv>(t, a, s);

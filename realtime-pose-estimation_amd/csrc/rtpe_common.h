@@ -116,6 +116,7 @@ struct ConvArgs {
   int dil;               // dilation
   int lo_y, lo_x;        // min tap offsets
   int halo_h, halo_w;    // staged input tile (pixels)
+  int rowb;              // LDS bytes per staged tile row (>= halo_w * pstride: conv_row_pitch)
   int cc;                // input channels staged per chunk
   int n_cchunks;         // ceil(cin / cc)
   int kc;                // 32-wide k chunks per channel chunk = ceil(ntaps*cc/32)
@@ -164,6 +165,9 @@ struct ConvGeom {       // logical layer, independent of the batch
 ConvPlan conv_make_plan(const ConvGeom& g);
 // choose the tile for a position grid (N images of H_pos x W_pos positions)
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos);
+// LDS bytes per row of the staged input tile of a tw-wide output tile: halo_w * pstride, padded (fp16) so that a
+// 16-pixel MFMA column tile which wraps to the next output row keeps the bank pattern of consecutive pixels
+int conv_row_pitch(const ConvPlan& p, int tw);
 void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector<ConvTile>* out);
 // pack fp16 weights (host) into fragment order; w is OIHW (IOHW 4x4 for deconv classes)
 void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w, void* packed);
