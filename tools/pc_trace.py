@@ -36,6 +36,8 @@ def main():
                                          be[1].ctypes.data_as(fpt), y.data_ptr(), st))
     torch.cuda.synchronize()
     raw = ctypes.CDLL(nat.lib()._name)
+    if not hasattr(raw, "rtpe_diag_pc_trace"):
+        sys.exit("tools/pc_trace.py needs a diagnostic build: RTPE_BUILD_DEFS=-DRTPE_DIAG (touch csrc/conv_block.hip first)")
     buf = (ctypes.c_ulonglong * 512)()
     assert raw.rtpe_diag_pc_trace(buf) == 0
     t = np.array(buf, dtype=np.int64).reshape(8, 64)
