@@ -136,9 +136,11 @@ struct AxisTab {
 
 // returns false (and leaves `raw` unfilled) only when the caller passed `pos_flag` and no source value under
 // the tile is positive
+constexpr int kTRows = 24;          // source rows of a tile kept as horizontally interpolated rows (separable sampling)
+
 template <class Map>
 __device__ __forceinline__ bool fill_raw(const Map& m, int plane, int h, int w, int y0, int x0, int pad, float* raw,
-                                         AxisTab*, AxisTab*, float*, int, int* = nullptr) {
+                                         AxisTab*, AxisTab*, float*, int, int* = nullptr, float* = nullptr) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH * PW; i += 256) {
     const int py = i / PW, px = i - py * PW;
@@ -151,7 +153,7 @@ __device__ __forceinline__ bool fill_raw(const Map& m, int plane, int h, int w, 
 template <>
 __device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int plane, int h, int w, int y0, int x0,
                                                       int pad, float* raw, AxisTab* ty, AxisTab* tx, float* stage,
-                                                      int stage_floats, int* pos_flag) {
+                                                      int stage_floats, int* pos_flag, float* tbuf) {
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
   for (int i = threadIdx.x; i < PH + PW; i += 256) {
     const bool isy = i < PH;
@@ -205,6 +207,50 @@ __device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int 
     const float t1 = __builtin_fmaf(v10, lx0, v11 * lx1);
     return __builtin_fmaf(t0, ly0, t1 * ly1);
   };
+  if (tbuf != nullptr && staged && er <= kTRows && (PW & 3) == 0) {
+    // Separable form (5x5 window path): T(r, px) = fma(v(r, c0), lx0, v(r, c1) * lx1) depends on the SOURCE row r and
+    // the output column only, and every source row serves ~4 output rows (as their upper or lower row): the
+    // horizontal step is done once per (source row, column), the vertical step fma(T(r0), ly0, T(r1) * ly1) takes
+    // 4 columns per thread with 16-byte LDS accesses.  The same operations on the same operands as
+    // BilinearMap::at: bit-equal.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {
+      const int c0 = tx->i0[lane], c1 = tx->i1[lane];
+      const float lx0 = tx->l0[lane], lx1 = tx->l1[lane];
+      for (int r = wv; r < er; r += 4) {
+        const float* srow = stage + r * ec - sc0;
+        tbuf[r * PW + lane] = c0 < 0 ? 0.f : __builtin_fmaf(srow[c0], lx0, srow[c1] * lx1);
+      }
+      const int extra = PW - 64;                           // 2 * pad columns
+      for (int i = threadIdx.x; i < er * extra; i += 256) {
+        const int r = i / extra, px = 64 + i - r * extra;
+        const int e0 = tx->i0[px], e1 = tx->i1[px];
+        const float* srow = stage + r * ec - sc0;
+        tbuf[r * PW + px] = e0 < 0 ? 0.f : __builtin_fmaf(srow[e0], tx->l0[px], srow[e1] * tx->l1[px]);
+      }
+    }
+    __syncthreads();
+    const int groups = PW >> 2;                            // 4 columns per thread and row
+    for (int i = threadIdx.x; i < PH * groups; i += 256) {
+      const int py = i / groups, cg = i - py * groups;
+      const int r0 = ty->i0[py];
+      float4 o = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (r0 >= 0) {
+        const int r1 = ty->i1[py];
+        const float ly0 = ty->l0[py], ly1 = ty->l1[py];
+        const float4 a = *reinterpret_cast<const float4*>(tbuf + (r0 - sr0) * PW + 4 * cg);
+        const float4 bq = *reinterpret_cast<const float4*>(tbuf + (r1 - sr0) * PW + 4 * cg);
+        const int x = x0 - pad + 4 * cg;                   // columns outside the image stay -inf
+        if ((unsigned)(x + 0) < (unsigned)w) o.x = __builtin_fmaf(a.x, ly0, bq.x * ly1);
+        if ((unsigned)(x + 1) < (unsigned)w) o.y = __builtin_fmaf(a.y, ly0, bq.y * ly1);
+        if ((unsigned)(x + 2) < (unsigned)w) o.z = __builtin_fmaf(a.z, ly0, bq.z * ly1);
+        if ((unsigned)(x + 3) < (unsigned)w) o.w = __builtin_fmaf(a.w, ly0, bq.w * ly1);
+      }
+      *reinterpret_cast<float4*>(raw + py * PW + 4 * cg) = o;
+    }
+    __syncthreads();                                       // `stage` becomes the row-max buffer again
+    return true;
+  }
   // lane = column (its axis entry stays in registers), wave = every 4th row (its axis entry is wave-uniform):
   // per sample only the four taps and the result touch LDS - with one table look-up per sample and axis the
   // kernel was bound by the LDS instruction rate.  Columns 64.. of the padded tile go in one extra pass.
@@ -231,11 +277,31 @@ __device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int 
 template <class Map>
 __device__ __forceinline__ bool nms_tile(const Map& m, int plane, int h, int w, int y0, int x0, int pad,
                                          float* raw, float* rowmax, AxisTab* ty, AxisTab* tx, int* pos_flag = nullptr,
-                                         int rowmax_floats = (kTH + 2 * kMaxPad) * kTW) {
+                                         int rowmax_floats = (kTH + 2 * kMaxPad) * kTW, float* tbuf = nullptr) {
   // raw: (kTH+2p) x (kTW+2p) samples (-inf outside the image); rowmax: horizontal window max
   const int PW = kTW + 2 * pad, PH = kTH + 2 * pad;
-  if (!fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, rowmax_floats, pos_flag)) return false;
+  if (!fill_raw(m, plane, h, w, y0, x0, pad, raw, ty, tx, rowmax, rowmax_floats, pos_flag, tbuf)) return false;
   __syncthreads();
+  if (pad == 2 && tbuf != nullptr) {
+    // 5-wide window, 8 outputs per thread from 12 inputs (three 16-byte reads, two 16-byte writes) instead of
+    // five 4-byte reads per output; max is exact, so any grouping gives the same bits
+    for (int i = threadIdx.x; i < PH * (kTW / 8); i += 256) {
+      const int py = i / (kTW / 8), g8 = i - py * (kTW / 8);
+      const float4* src = reinterpret_cast<const float4*>(raw + py * PW + 8 * g8);
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+      const float x[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+      float pr[11], o[8];
+#pragma unroll
+      for (int j = 0; j < 11; ++j) pr[j] = fmaxf(x[j], x[j + 1]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaxf(pr[j], pr[j + 2]), x[j + 4]);
+      float4* dst = reinterpret_cast<float4*>(rowmax + py * kTW + 8 * g8);
+      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    __syncthreads();
+    return true;
+  }
   for (int i = threadIdx.x; i < PH * kTW; i += 256) {
     const int py = i / kTW, px = i - py * kTW;
     float v = raw[py * PW + px];
@@ -271,11 +337,14 @@ __global__ void __launch_bounds__(256) nms_kernel(Map m, int h, int w, int pad, 
 // top-K, phase 1: per tile, the K best positive local maxima as sorted keys
 // ---------------------------------------------------------------------------
 template <class Map, int PAD>     // PAD >= 0: the NMS padding as a compile-time constant (divisions by PW become shifts/muls)
-__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad_rt, int K, u64* cand) {
+__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad_rt, int K, u64* cand, int fast) {
   const int pad = PAD >= 0 ? PAD : pad_rt;
   constexpr int kP = PAD >= 0 ? PAD : kMaxPad;           // the common 5x5 window needs 19 KiB of tiles, not 21.8: one more block per CU
-  __shared__ float raw[(kTH + 2 * kP) * (kTW + 2 * kP)];
-  __shared__ float rowmax[(kTH + 2 * kP) * kTW];
+  __shared__ __attribute__((aligned(16))) float raw[(kTH + 2 * kP) * (kTW + 2 * kP)];
+  __shared__ __attribute__((aligned(16))) float rowmax[(kTH + 2 * kP) * kTW];
+  constexpr bool kFast = PAD == 2;                       // 5x5 window: separable sampling, register-blocked max passes
+  __shared__ __attribute__((aligned(16))) float tbuf_s[kFast ? kTRows * (kTW + 4) : 4];
+  float* const tbuf = kFast && fast ? tbuf_s : nullptr;
   __shared__ u64 red[4];
   const int tiles_x = (w + kTW - 1) / kTW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
@@ -284,13 +353,42 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
   __shared__ u64 clist[kMaxCand];
   __shared__ int ccount, any_positive;
   if (threadIdx.x == 0) { ccount = 0; any_positive = 0; }
-  if (!nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx, &any_positive, (kTH + 2 * kP) * kTW)) {
+  if (!nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx, &any_positive, (kTH + 2 * kP) * kTW, tbuf)) {
     u64* outp0 = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;       // nothing positive under this tile
     for (int r = threadIdx.x; r < K; r += 256) outp0[r] = 0;
     return;
   }
   const int PW = kTW + 2 * pad;
   u64 mine[8];   // this thread's 8 pixels as keys (0 = not a positive local maximum)
+  if (tbuf != nullptr) {
+    // thread = 2 rows x 4 columns: six 16-byte reads of the row maxima give both vertical windows
+    const int ry = threadIdx.x >> 4, cg = threadIdx.x & 15;
+    const int ly = 2 * ry, lx = 4 * cg;
+    float4 rm[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) rm[d] = *reinterpret_cast<const float4*>(rowmax + (ly + d) * kTW + lx);
+    const float mid[4] = {fmaxf(fmaxf(rm[1].x, rm[2].x), fmaxf(rm[3].x, rm[4].x)), fmaxf(fmaxf(rm[1].y, rm[2].y), fmaxf(rm[3].y, rm[4].y)),
+                          fmaxf(fmaxf(rm[1].z, rm[2].z), fmaxf(rm[3].z, rm[4].z)), fmaxf(fmaxf(rm[1].w, rm[2].w), fmaxf(rm[3].w, rm[4].w))};
+    const float top[4] = {rm[0].x, rm[0].y, rm[0].z, rm[0].w}, bot[4] = {rm[5].x, rm[5].y, rm[5].z, rm[5].w};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const float2* c2 = reinterpret_cast<const float2*>(raw + (ly + rr + 2) * PW + lx + 2);   // 8-byte aligned
+      const float2 va = c2[0], vb = c2[1];
+      const float v4[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float mx = fmaxf(mid[j], rr == 0 ? top[j] : bot[j]);
+        const int y = y0 + ly + rr, x = x0 + lx + j;
+        u64 key = 0;
+        if (y < h && x < w && mx == v4[j] && v4[j] > 0.f) key = make_key(v4[j], (unsigned)(y * w + x));
+        mine[rr * 4 + j] = key;
+        if (key != 0) {
+          const int pos = atomicAdd(&ccount, 1);
+          if (pos < kMaxCand) clist[pos] = key;
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int i = threadIdx.x + q * 256;
@@ -308,6 +406,7 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
       const int pos = atomicAdd(&ccount, 1);
       if (pos < kMaxCand) clist[pos] = key;
     }
+  }
   }
   __syncthreads();
   u64* outp = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;
@@ -941,10 +1040,12 @@ static int topk_run(const Map& m, const TagMap& tm, int planes, int tag_shared_j
   RTPE_REQUIRE(scratch_bytes >= topk_scratch(planes, h, w, K), "topk: scratch too small");
   const int tiles = ((h + kTH - 1) / kTH) * ((w + kTW - 1) / kTW);
   u64* cand = reinterpret_cast<u64*>(scratch);
+  // RTPE_TOPK_FAST=0: the 5x5 path without the separable sampling / register-blocked max passes (same bits)
+  static const int fast = getenv("RTPE_TOPK_FAST") ? atoi(getenv("RTPE_TOPK_FAST")) : 1;
   if (pad == 2)
-    hipLaunchKernelGGL((topk_tile_kernel<Map, 2>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
+    hipLaunchKernelGGL((topk_tile_kernel<Map, 2>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand, fast);
   else
-    hipLaunchKernelGGL((topk_tile_kernel<Map, -1>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand);
+    hipLaunchKernelGGL((topk_tile_kernel<Map, -1>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand, 0);
   RTPE_HIP_CHECK(hipGetLastError());
   size_t lds = 32 + (size_t)tiles * K * 8;
   if (lds > 150 * 1024 || tiles <= 8 * 256) lds = 32;     // the head merge (tiles <= kOwn * 256) needs no copy of the lists

@@ -133,37 +133,72 @@ class TeacherPipeline:
         hw = tuple(out_hw) if out_hw is not None else tuple(images.shape[2:])
         return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
 
-    def stream(self, batches, out_hw=None, on_forward=None):
-        """Software-pipelined loop over an iterable of (N,3,H,W) GPU batches.  Everything goes to
-        ONE stream, in the order  F(k) R(k-1) T(k)  (forward, adjust+refine of the previous batch,
-        fused top-k): the network kernels fill the chip, so decode kernels on a side stream only
-        ran once the forward queue was empty.  The host part of the decode of batch k-1 (tag
-        matching on the host cores) runs while the GPU executes F(k), whose launches are already
-        queued; the GPU never waits for the host.  The decode tables travel through pinned host
-        memory that the kernels read and write in place (no copy commands in the stream).
+    def stream(self, batches, out_hw=None, on_forward=None, decode_stream=None):
+        """Software-pipelined loop over an iterable of (N,3,H,W) GPU batches, in the order
+        F(k) R(k-1) T(k)  (forward, adjust+refine of the previous batch, fused top-k).  The host part
+        of the decode of batch k-1 (tag matching on the host cores) runs while the GPU executes F(k),
+        whose launches are already queued; the GPU never waits for the host.  The decode tables travel
+        through pinned host memory that the kernels read and write in place (no copy commands in the
+        stream).
+
+        ``decode_stream``: ``None`` (default) = environment ``RTPE_DECODE_STREAM`` (default "side");
+        ``"side"`` puts R and T on a second, high-priority HIP stream that waits for F(k) by event: the
+        network's ~330 kernels per forward leave the chip partly idle at every kernel boundary (a
+        persistent one-workgroup-per-CU kernel ends with its slowest workgroup), and the decode's many
+        small workgroups fill those gaps instead of costing their own ~0.9 ms of stream time;
+        ``"same"`` keeps everything on the current stream.
+
         Yields one ``[(people, scores)] * N`` list per batch, in order, two steps after the batch
         was submitted.  ``on_forward(k, x)`` may replace the plain forward (bench.py records op
         events).  Keep the host thread pools small (``torch.set_num_threads``): a burst of idle-
         spinning OpenMP threads can exhaust a container's CPU quota and stall the launches."""
+        import os
+        mode = decode_stream or os.environ.get("RTPE_DECODE_STREAM", "side")
+        if mode not in ("side", "same"):
+            raise ValueError("decode_stream must be 'side' or 'same', not %r" % (mode,))
+        main = torch.cuda.current_stream(self.device)
+        side = None
+        if mode == "side":
+            side = self.__dict__.get("_decode_stream")
+            if side is None:
+                side = self._decode_stream = torch.cuda.Stream(self.device, priority=-1)
         topk_done = None      # batch k-1: top-k enqueued
         refine_done = None    # batch k-2: refine enqueued
         P = self.parser
+
+        def on_decode_stream(fn, *args, after=None, uses=()):
+            if side is None:
+                return fn(*args)
+            with torch.cuda.stream(side):
+                if after is not None:
+                    side.wait_event(after)
+                for t in uses:                  # allocated on the main stream, read on the side stream
+                    t.record_stream(side)
+                return fn(*args)
+
         with torch.no_grad():
             for k, x in enumerate(batches):
                 preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
                 hw = tuple(out_hw) if out_hw is not None else tuple(x.shape[2:])
+                f_done = None
+                if side is not None:
+                    f_done = torch.cuda.Event()
+                    f_done.record(main)
                 if topk_done is not None:
-                    P.lowres_match(topk_done)          # host matching overlaps F(k) on the GPU
-                st = P.lowres_topk(refined, preds[:, NUM_HEATMAPS:], hw)
+                    on_decode_stream(P.lowres_match, topk_done)     # host matching overlaps F(k) on the GPU
+                st = on_decode_stream(P.lowres_topk, refined, preds[:, NUM_HEATMAPS:], hw, after=f_done,
+                                      uses=(preds, refined))
                 if refine_done is not None:
                     yield P.lowres_finish(refine_done)
                 refine_done, topk_done = topk_done, st
             if topk_done is not None:
-                P.lowres_match(topk_done)
+                on_decode_stream(P.lowres_match, topk_done)
             if refine_done is not None:
                 yield P.lowres_finish(refine_done)
             if topk_done is not None:
                 yield P.lowres_finish(topk_done)
+            if side is not None:
+                main.wait_stream(side)          # whoever continues on the main stream sees the decode as done
 
     def gather(self, image_ids, results, equal_counts=False):
         """all-gather of the decoded keypoints over the process group (RCCL).  ``equal_counts``:
