@@ -218,7 +218,17 @@ conv_stream_kernel(const ConvArgs a) {
         const_cast<_Float16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const int rowslots = a.halo_w * kSlots;
     const int rowbytes = a.rowb;
-    auto issue = [&](int s, int r0, int r1) {           // halo rows [r0, r1) of the tile of stage s
+    // A tile request in two halves: the address arithmetic of stage s + P is done BEFORE this loader waits for
+    // its rows of the current tile and for the barrier (it would otherwise sit between the barrier that frees
+    // the buffer and the first request, on the path that bounds the stage: a request needs ~2 us to land and
+    // can only be made one stage ahead with two buffers); after the barrier nothing but the requests is left.
+    struct TileReq {
+      uint32_t voff[4];                                  // per-lane column part, one per DMA instruction of a row
+      int soff0, soff_row;                               // scalar offset of halo row 0, bytes between rows
+      int row_lo, row_hi;                                // halo rows [row_lo, row_hi) lie inside the image
+      char* buf;
+    };
+    auto prepare = [&](int s, TileReq& q) {
       int tile, cb;
       um.get(s >> sh, &tile, &cb);
       const int chunk = s & (ncc - 1);
@@ -230,30 +240,37 @@ conv_stream_kernel(const ConvArgs a) {
       const uint32_t tyi = fdiv(t, a.div_tiles_x);
       const uint32_t txi = t - tyi * a.tiles_x;
       const int iy0 = (int)tyi * a.th * a.in_mul + a.lo_y, ix0 = (int)txi * a.tw * a.in_mul + a.lo_x;
-      // per-lane column part of the address, one value per DMA instruction of a row
-      uint32_t voff[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int q = k * 64 + lane;
-        const int hx = q / kSlots, sl = q - hx * kSlots;
+        const int qq = k * 64 + lane;
+        const int hx = qq / kSlots, sl = qq - hx * kSlots;
         const int ix = ix0 + hx;
         const bool ok = (unsigned)ix < (unsigned)a.W_in && cbase + sl * 8 < a.cin;
-        voff[k] = ok ? (uint32_t)(ix * a.in_ld + sl * 8) * 2u : 0x80000000u;
+        q.voff[k] = ok ? (uint32_t)(ix * a.in_ld + sl * 8) * 2u : 0x80000000u;
       }
-      char* buf = tiles + (s % NB) * a.buf_bytes;
-      const int img_row0 = (int)n * a.H_in;
+      q.buf = tiles + (s % NB) * a.buf_bytes;
+      q.soff_row = a.W_in * a.in_ld * 2;
+      q.soff0 = (((int)n * a.H_in + iy0) * a.W_in * a.in_ld + chunk_off) * 2;
+      q.row_lo = iy0 < 0 ? -iy0 : 0;
+      q.row_hi = a.H_in - iy0;                            // rows r with iy0 + r < H_in
+    };
+    auto fire = [&](const TileReq& q, int r0, int r1) {  // halo rows [r0, r1)
       for (int r = r0; r < r1; ++r) {
-        const int iy = iy0 + r;
-        const bool row_ok = (unsigned)iy < (unsigned)a.H_in;
-        const int soff = row_ok ? ((img_row0 + iy) * a.W_in * a.in_ld + chunk_off) * 2 : 0;
-        char* dst = buf + r * rowbytes;
+        const bool row_ok = r >= q.row_lo && r < q.row_hi;
+        const int soff = row_ok ? q.soff0 + r * q.soff_row : 0;
+        char* dst = q.buf + r * rowbytes;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (k * 64 < rowslots && k * 64 + lane < rowslots && !(a.ablate & 4))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + k * 1024), 16,
-                                                     (int)(row_ok ? voff[k] : 0x80000000u), soff, 0, 0);
+                                                     (int)(row_ok ? q.voff[k] : 0x80000000u), soff, 0, 0);
         }
       }
+    };
+    auto issue = [&](int s, int r0, int r1) {
+      TileReq q;
+      prepare(s, q);
+      fire(q, r0, r1);
     };
     // both loaders work on EVERY tile (one half of its rows each): two instruction streams feed the
     // memory pipeline, and a tile is requested P = NB - 1 stages before it is multiplied
@@ -269,18 +286,20 @@ conv_stream_kernel(const ConvArgs a) {
 #endif
     for (int s = 0; s < S; ++s) {
       SSTAMP(t0);
+      const bool more = s + P < S;
+      TileReq q;
+      prepare(more ? s + P : S - 1, q);                  // (no memory operations: before the waits)
       // this loader's part of tile s has landed; with P == 2 its part of tile s+1 may still be in flight
       if (P == 2 && s + 1 < S) wait_vmcnt(n_part);
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SSTAMP(t1);
       RTPE_SBARRIER();                                   // M(s): buffer (s-1) % NB is free
       SSTAMP(t2);
-      const bool more = s + P < S;
-      if (more) issue(s + P, ra, rmid);
+      if (more) fire(q, ra, rmid);
       SSTAMP(t3);
       if (!resident) {
         RTPE_SBARRIER();                                 // H(s)
-        if (more) issue(s + P, rmid, rb);
+        if (more) fire(q, rmid, rb);
       }
       if ((s & (ncc - 1)) == ncc - 1) RTPE_SBARRIER();   // E(s)
 #ifdef RTPE_CONV_STAMPS

@@ -10,7 +10,8 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
                     c_size_t, c_void_p)
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "librtpe_hip.so")
+# RTPE_LIBRARY: another build of the same ABI (A/B measurements of two builds on one GPU box)
+LIB_PATH = os.environ.get("RTPE_LIBRARY") or os.path.join(_PKG_DIR, "librtpe_hip.so")
 
 RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
 OP_STEM, OP_CONV, OP_DECONV, OP_FUSE, OP_CAST, OP_AVGPOOL, OP_SE, OP_CAM_COMBINE, OP_SIGMOID_ADD = range(9)
