@@ -29,6 +29,22 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// conv accumulator -> fp16 (the conv's output tensor) -> BN in fp32 -> fp16, the wrapper's rounding points.  The
+// fp16 values feed the fma directly (v_fma_mix_f32 converts its first operand on the way in: the same fp32 fma on
+// the same operands as convert + v_pk_fma_f32, one instruction less per pair); the empty asm keeps the compiler from
+// folding the final conversion into v_fma_mixlo_f16, which would round the exact a*b+c once instead of twice.
+__device__ __forceinline__ half4 bn_round(const float4v v, const float4v al, const float4v be) {
+  const half2v h0 = __builtin_convertvector(float2v{v[0], v[1]}, half2v);
+  const half2v h1 = __builtin_convertvector(float2v{v[2], v[3]}, half2v);
+  float r0 = __builtin_fmaf((float)h0[0], al[0], be[0]);
+  float r1 = __builtin_fmaf((float)h0[1], al[1], be[1]);
+  float r2 = __builtin_fmaf((float)h1[0], al[2], be[2]);
+  float r3 = __builtin_fmaf((float)h1[1], al[3], be[3]);
+  asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+  const half2v o0 = __builtin_convertvector(float2v{r0, r1}, half2v), o1 = __builtin_convertvector(float2v{r2, r3}, half2v);
+  return half4{o0[0], o0[1], o1[0], o1[1]};
+}
 typedef short short8 __attribute__((ext_vector_type(8)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
@@ -304,15 +320,8 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
         const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const float4v v = acc1[m][nt];
-          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
-          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);      // conv output is fp16
-          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
-          lo = __builtin_elementwise_fma(lo, float2v{al1[m][0], al1[m][1]}, float2v{be1[m][0], be1[m][1]});
-          hi = __builtin_elementwise_fma(hi, float2v{al1[m][2], al1[m][3]}, float2v{be1[m][2], be1[m][3]});
-          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
-          half4 o{olo[0], olo[1], ohi[0], ohi[1]};
-          short4v b = __builtin_bit_cast(short4v, o);
+          const half4 o_bn = bn_round(acc1[m][nt], al1[m], be1[m]);
+          short4v b = __builtin_bit_cast(short4v, o_bn);
           b = b & ~(b >> 15);                                                                // ReLU on the sign bits
           if (!inside) b = b ^ b;                                                            // conv2's zero padding
           if (p < kMH * kMW)
@@ -376,14 +385,8 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_kernel(const
       for (int nt = 0; nt < kNT2; ++nt)
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const float4v v = acc2[m][nt];
-          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
-          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
-          lo = __builtin_elementwise_fma(lo, float2v{al2[m][0], al2[m][1]}, float2v{be2[m][0], be2[m][1]});
-          hi = __builtin_elementwise_fma(hi, float2v{al2[m][2], al2[m][3]}, float2v{be2[m][2], be2[m][3]});
-          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
-          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
+          const half4 o_bn = bn_round(acc2[m][nt], al2[m], be2[m]);
+          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = o_bn;
         }
       half8 ov[kNIT], rv[kNIT];
 #pragma unroll
@@ -636,15 +639,8 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
         const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const float4v v = acc1[m][nt];
-          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
-          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
-          lo = __builtin_elementwise_fma(lo, float2v{al1[m][0], al1[m][1]}, float2v{be1[m][0], be1[m][1]});
-          hi = __builtin_elementwise_fma(hi, float2v{al1[m][2], al1[m][3]}, float2v{be1[m][2], be1[m][3]});
-          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
-          half4 o{olo[0], olo[1], ohi[0], ohi[1]};
-          short4v b = __builtin_bit_cast(short4v, o);
+          const half4 o_bn = bn_round(acc1[m][nt], al1[m], be1[m]);
+          short4v b = __builtin_bit_cast(short4v, o_bn);
           b = b & ~(b >> 15);
           if (!inside) b = b ^ b;
           if (p < kMH * kMW)
@@ -676,14 +672,8 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
       for (int nt = 0; nt < kNT2; ++nt)
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const float4v v = acc2[m][nt];
-          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
-          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-          hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
-          lo = __builtin_elementwise_fma(lo, float2v{al2[m][0], al2[m][1]}, float2v{be2[m][0], be2[m][1]});
-          hi = __builtin_elementwise_fma(hi, float2v{al2[m][2], al2[m][3]}, float2v{be2[m][2], be2[m][3]});
-          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
-          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
+          const half4 o_bn = bn_round(acc2[m][nt], al2[m], be2[m]);
+          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = o_bn;
         }
       half8 ov[kNIT];
 #pragma unroll
@@ -976,13 +966,7 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
         const bool interior = py0 >= 1 && py0 + kPTH < a.H && px0 >= 1 && px0 + kPTW < a.W;
         auto bn_relu = [&](int m, int nt) __attribute__((always_inline)) {
           const float4v v = acc[m][nt];
-          float2v lo{v[0], v[1]}, hi2{v[2], v[3]};
-          lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-          hi2 = __builtin_convertvector(__builtin_convertvector(hi2, half2v), float2v);
-          lo = __builtin_elementwise_fma(lo, float2v{al1[m][0], al1[m][1]}, float2v{be1[m][0], be1[m][1]});
-          hi2 = __builtin_elementwise_fma(hi2, float2v{al1[m][2], al1[m][3]}, float2v{be1[m][2], be1[m][3]});
-          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi2, half2v);
-          half4 o{olo[0], olo[1], ohi[0], ohi[1]};
+          half4 o = bn_round(v, al1[m], be1[m]);
           short4v b = __builtin_bit_cast(short4v, o);
           return b & ~(b >> 15);
         };
@@ -1141,14 +1125,7 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
       const float4v al = bn.al[m], be = bn.be[m];
 #pragma unroll
       for (int nt = 0; nt < kPNT2; ++nt) {
-        const float4v vv = acc[m][nt];
-        float2v lo{vv[0], vv[1]}, hi2{vv[2], vv[3]};
-        lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-        hi2 = __builtin_convertvector(__builtin_convertvector(hi2, half2v), float2v);
-        lo = __builtin_elementwise_fma(lo, float2v{al[0], al[1]}, float2v{be[0], be[1]});
-        hi2 = __builtin_elementwise_fma(hi2, float2v{al[2], al[3]}, float2v{be[2], be[3]});
-        const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi2, half2v);
-        *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = half4{olo[0], olo[1], ohi[0], ohi[1]};
+        *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kRowB + m * 32 + ge * 8) = bn_round(acc[m][nt], al, be);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the residual pieces have landed (requested an interval ago)

@@ -42,6 +42,22 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// conv accumulator -> fp16 (the conv's output tensor) -> BN in fp32 -> fp16, the wrapper's rounding points.  The
+// fp16 values feed the fma directly (v_fma_mix_f32 converts its first operand on the way in: the same fp32 fma on
+// the same operands as convert + v_pk_fma_f32, one instruction less per pair); the empty asm keeps the compiler from
+// folding the final conversion into v_fma_mixlo_f16, which would round the exact a*b+c once instead of twice.
+__device__ __forceinline__ half4 bn_round(const float4v v, const float4v al, const float4v be) {
+  const half2v h0 = __builtin_convertvector(float2v{v[0], v[1]}, half2v);
+  const half2v h1 = __builtin_convertvector(float2v{v[2], v[3]}, half2v);
+  float r0 = __builtin_fmaf((float)h0[0], al[0], be[0]);
+  float r1 = __builtin_fmaf((float)h0[1], al[1], be[1]);
+  float r2 = __builtin_fmaf((float)h1[0], al[2], be[2]);
+  float r3 = __builtin_fmaf((float)h1[1], al[3], be[3]);
+  asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+  const half2v o0 = __builtin_convertvector(float2v{r0, r1}, half2v), o1 = __builtin_convertvector(float2v{r2, r3}, half2v);
+  return half4{o0[0], o0[1], o1[0], o1[1]};
+}
 typedef short short8 __attribute__((ext_vector_type(8)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 
@@ -519,15 +535,16 @@ conv_stream_kernel(const ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const float4v v = acc[m][nt];
-          float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+          half4 o;
           if (RC) {                                      // the conv output is an fp16 tensor
-            lo = __builtin_convertvector(__builtin_convertvector(lo, half2v), float2v);
-            hi = __builtin_convertvector(__builtin_convertvector(hi, half2v), float2v);
+            o = bn_round(v, al[m], be[m]);
+          } else {
+            float2v lo{v[0], v[1]}, hi{v[2], v[3]};
+            lo = __builtin_elementwise_fma(lo, float2v{al[m][0], al[m][1]}, float2v{be[m][0], be[m][1]});
+            hi = __builtin_elementwise_fma(hi, float2v{al[m][2], al[m][3]}, float2v{be[m][2], be[m][3]});
+            const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+            o = half4{olo[0], olo[1], ohi[0], ohi[1]};
           }
-          lo = __builtin_elementwise_fma(lo, float2v{al[m][0], al[m][1]}, float2v{be[m][0], be[m][1]});
-          hi = __builtin_elementwise_fma(hi, float2v{al[m][2], al[m][3]}, float2v{be[m][2], be[m][3]});
-          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
-          const half4 o{olo[0], olo[1], ohi[0], ohi[1]};
           *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * ROWB + m * 32 + ge * 8) = o;
           if (NCHW) {                                    // heads: NCHW straight from the registers
             const uint32_t p = (wv * NT + nt) * 16 + re;
