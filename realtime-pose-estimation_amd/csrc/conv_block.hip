@@ -1025,12 +1025,13 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
   const int hi4 = hi * (kPMRow - 3 * kPS), hi13 = -hi * (2 * kPMRow + 2 * kPS + 96);
   // 16-byte pieces of this wave's two output rows: piece c = it * 64 + lane -> slab pixel c / 6 (row c / 96 of
   // the pair, column (c / 6) % 16), slot c % 6.  Offsets in the slab, in x and in y (bytes from the pair's first pixel)
-  uint32_t ooffs[kPNIT], yoffr[kPNIT];
+  uint32_t ooffs[kPNIT], xoffr[kPNIT], yoffr[kPNIT];
 #pragma unroll
   for (int it = 0; it < kPNIT; ++it) {
     const int c = it * 64 + lane;
     const int pw = c / 6, slot = c - pw * 6;
     ooffs[it] = (uint32_t)(pw * kRowB + slot * 16);
+    xoffr[it] = (uint32_t)(((pw >> 4) * a.W + (pw & 15)) * a.in_ld * 2 + slot * 16);
     yoffr[it] = (uint32_t)(((pw >> 4) * a.W + (pw & 15)) * a.out_ld * 2 + slot * 16);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // W1, BN2, both x tiles, w2 registers
@@ -1103,15 +1104,9 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
     int py0, px0;
     unit_origin(v, &n, &py0, &px0);
     const int pix0 = ((int)n * a.H + py0 + cw * kPNT2) * a.W + px0;
-    int lane_r = lane;
-    asm volatile("" : "+v"(lane_r));                       // offsets recomputed per unit: no registers held
 #pragma unroll
-    for (int it = 0; it < kPNIT; ++it) {
-      const int c = it * 64 + lane_r;
-      const int pw = c / 6, slot = c - pw * 6;
-      const int voff = ((pw >> 4) * a.W + (pw & 15)) * a.in_ld * 2 + slot * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(res + it * 1024), 16, voff, pix0 * a.in_ld * 2, 0, 0);
-    }
+    for (int it = 0; it < kPNIT; ++it)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(res + it * 1024), 16, (int)xoffr[it], pix0 * a.in_ld * 2, 0, 0);
     return reinterpret_cast<char*>(a.y + (size_t)pix0 * a.out_ld);
   };
   // BN2 of the accumulators, transposed through this wave's slab, + x, ReLU, store
