@@ -703,26 +703,33 @@ __global__ void __launch_bounds__((kWaves + kLoad) * 64) conv_block_rw_kernel(co
 // pipe is busy 42 % of the kernel and SQ_VALU_MFMA_COEXEC is ~0.7 %: the two epilogues (BN / ReLU / transposition
 // / stores, ~45 % of a unit) never run beside matrix work, because the four MFMA waves move through the phases
 // together.  Here the workgroup has EIGHT waves, two per SIMD, whose phases are complementary:
-//   * producers P0-3, interval i: conv1 of unit i (x tile -> accumulators), then its epilogue (BN1 + ReLU -> mid);
-//   * consumers C0-3, interval i: request the x tile of unit i+1 (LDS-DMA; there are no loader waves), epilogue of
-//     unit i-2 (BN2, transposition, + x, ReLU, stores) - VALU / LDS / memory work while the producers' MFMAs own
-//     the matrix pipe - then conv2 of unit i-1 while the producers are in THEIR epilogue.
+//   * producers P0-3, interval i: conv1 of unit i (x tile -> accumulators), request of the x tile of unit i+1
+//     (LDS-DMA; there are no loader waves), then conv1's epilogue (BN1 + ReLU -> mid tile);
+//   * consumers C0-3, interval i: epilogue of unit i-2 (BN2, transposition, + x, ReLU, stores) - VALU / LDS / memory
+//     work while the producers' MFMAs own the matrix pipe - then conv2 of unit i-1 while the producers are in THEIR
+//     epilogue.
 // ONE workgroup barrier per unit.  What makes it fit the 160 KiB of LDS: 8 x 16 output tiles (conv1 region
 // 10 x 18 = 180 pixels = 11.25 MFMA column tiles: 3 per producer wave, 94 % useful), and conv2's weight fragments
 // live in the consumer waves' REGISTERS for the whole kernel (14 k-steps x 3 row tiles x 4 VGPRs = 168 of 256) -
 // only conv1's 42 KiB sit in LDS:
 //   W1 42 KiB | x tile (12 rows x 2,240 B) x 2 = 52.5 KiB | mid tile (10 x 18 px) x 2 = 33.75 KiB | output slabs 14 KiB
+//   | residual slabs 12 KiB | BN2 0.4 KiB = 154.6 KiB
 // x-tile rows have a 2,240 B pitch (20 pixels = 1,920 B + padding): every tile request is two full-wave LDS-DMA
-// instructions per row with no lane masked off (the 8 spare lanes fetch out-of-range -> zeros into the padding),
-// so the request is straight-line code and the compiler's own s_waitcnt bookkeeping stays exact.
-// Buffers alternate by unit parity: in interval i the producers read X[i&1] and write MID[i&1], the consumers
-// read MID[(i-1)&1] and refill X[(i+1)&1], whose last reader (conv1 of unit i-1) finished before the barrier.
+// instructions per row with no lane masked off (the 8 spare lanes fetch out-of-range -> zeros into the padding):
+// straight-line code.  The request's address arithmetic is done while the producer waits at the barrier, the
+// requests themselves go out right after the k loop (in flight during the k loop they slow its LDS reads by ~15 %)
+// and are waited for (vmcnt(0): a producer has no other memory operations) before the next barrier.
+// Buffers alternate by unit parity: in interval i the producers read X[i&1], write MID[i&1] and refill X[(i+1)&1],
+// whose last reader (their own conv1 of unit i-1) finished before the barrier; the consumers read MID[(i-1)&1].
 // The residual is NOT taken from the x tile (it would have to be held for two intervals): each consumer wave
 // re-requests its 3 x 16 B per lane from global memory (an L2 hit: the tile was fetched by the same XCD shortly
-// before) by LDS-DMA into a 3 KiB slab of its own one interval ahead - no registers, no exposed latency.
-// Same k order, same rounding points: bit-identical to the other variants.  Shapes: H % 8 == 0 and W % 16 == 0
-// (every tile complete: the consumers' store count per unit is then a constant, which the counted wait on the
-// DMA relies on); other shapes run the resident-weights variant.
+// before) by LDS-DMA into a 3 KiB slab of its own one interval ahead - no registers, no exposed latency; BN2's
+// parameters are fetched from LDS one interval ahead as well.
+// Same k order, same rounding points: bit-identical to the other variants.  Shapes: H % 8 == 0 and W % 16 == 0 (every
+// tile complete: no partial-tile handling in the request, mid and store paths); other shapes run the
+// resident-weights variant.  A consumer's loop body contains no branch around memory operations: the compiler's
+// s_waitcnt pass takes the minimum over paths and would wait for requests that were just issued.
+// s_setprio on either role was measured and changes nothing (tools/probes/coissue_probe.hip): not used.
 namespace {
 constexpr int kPTH = 8, kPTW = 16;                    // output tile
 constexpr int kPMH = kPTH + 2, kPMW = kPTW + 2;       // conv1 region = mid tile (10 x 18 = 180 px)
@@ -742,11 +749,6 @@ constexpr int kPOffBn = kPOffObuf + 4 * kPObuf;
 constexpr int kPOffRes = kPOffBn + 96 * 4;            // residual pieces: 3 KiB per consumer wave
 constexpr int kLdsPC = kPOffRes + 4 * 3072;           // 158,336
 constexpr int kPNIT = kPNT2 * 16 * 6 / 64;            // 3 pieces of 16 bytes per consumer lane
-#ifdef RTPE_PC_PRIO
-constexpr int kPrioVector = RTPE_PC_PRIO;
-#else
-constexpr int kPrioVector = 2;
-#endif
 static_assert(kPXW * 6 <= 128 && kPXRow >= 128 * 16, "an x-tile row is two full-wave requests");
 static_assert(kPMH * kPMW <= 4 * kPNT1 * 16, "conv1 region fits the producers' column tiles");
 }
@@ -783,11 +785,6 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
   const int tiles_xcd = min(per_xcd, n_tiles - t_begin);
   const int U = jw < tiles_xcd ? (tiles_xcd - jw + G - 1) / G : 0;
   if (U == 0) return;
-  // Wave priorities: a dense MFMA stream (conv2: operands in registers) starves the partner wave's VALU / LDS /
-  // address work on the same SIMD although an MFMA holds the vector issue for only half of its cycles - measured
-  // (tools/pc_trace.py): the producers' epilogue ran 3x slower beside conv2 than alone.  So everything that is not
-  // a k loop runs at raised priority and takes the issue slots it needs; the k loop fills the rest.
-  __builtin_amdgcn_s_setprio(kPrioVector);
 #ifdef RTPE_DIAG
   const bool trace_on = blockIdx.x == 8 * 3 + 2 && a.H == 160;   // one workgroup in the middle of XCD 2
   if (trace_on) *reinterpret_cast<unsigned long long*>(smem + kLdsPC + tid * 8) = 0ull;
@@ -921,7 +918,6 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
         // operands are fetched TWO k-steps ahead (three register sets): with 3 x 3 MFMAs per k-step (144 cycles)
         // and the four producer waves reading in step, a fetch issued one step ahead is not back in time
         half8 af[3][kMT], bf[3][kPNT1];
-        __builtin_amdgcn_s_setprio(0);                     // see kPrioVector
 #pragma unroll
         for (int s0 = 0; s0 < 2; ++s0) {
 #pragma unroll
@@ -952,7 +948,6 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_setprio(kPrioVector);
       }
 #ifdef RTPE_DIAG
       if (!(a.ablate & 32))
@@ -1059,7 +1054,6 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
       return reinterpret_cast<const half8*>(ta[nt] + (k == 4 ? hi4 : k == 13 ? hi13 : 0) + koff(k, kPMRow));
     };
     half8 bf[3][kPNT2];                                    // fetched two k-steps ahead, as in conv1
-    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int s0 = 0; s0 < 2; ++s0)
 #pragma unroll
@@ -1085,7 +1079,6 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_s_setprio(kPrioVector);
   };
   // BN2 parameters of this lane's channels (m * 16 + g * 4 ... + 3): fetched from LDS one interval ahead
   struct Bn2 { float4v al[kMT], be[kMT]; };
