@@ -1226,6 +1226,30 @@ def test_block_fusion_does_not_change_the_network_output(nat, teacher, tmp_path)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
 
 
+def test_block_kernel_variants_do_not_change_the_network_output(nat, teacher):
+    """the three fused BasicBlock kernels (producer / consumer: the default where tiles are complete; resident
+    weights; weight ring) are selected at run time: the whole network must give the SAME bits with each, at a size
+    where the default kernel runs on both 48-channel resolutions (64x96 and 128x192) and at one where it cannot
+    (a /4 map of 40x56: 56 % 16 != 0)"""
+    model, sd = teacher("W2")
+    L = nat.lib()
+    for hw in ((256, 384), (160, 224)):
+        x = synth.make_images(2, hw[0], hw[1], seed=23).to("cuda:0")
+        outs = []
+        for pc, ring in ((1, 0), (0, 0), (0, 1)):
+            nat.check(L.rtpe_set_option(b"block_pc", pc))
+            nat.check(L.rtpe_set_option(b"block_ring", ring))
+            try:
+                with torch.no_grad():
+                    preds, refined = model(x)
+                outs.append((preds.cpu().numpy(), refined.cpu().numpy()))
+            finally:
+                nat.check(L.rtpe_set_option(b"block_pc", 1))
+                nat.check(L.rtpe_set_option(b"block_ring", 0))
+        for p, r in outs[1:]:
+            assert np.array_equal(p, outs[0][0]) and np.array_equal(r, outs[0][1])
+
+
 def test_plane_major_inner_tensors_do_not_change_the_network_output(nat, teacher, tmp_path):
     """the inner tensors of the 96/192/384-channel BasicBlock chains are kept as [C/48][N][H][W][48] when the
     streaming kernel runs every conv around them; a second process with RTPE_PLANE_MAJOR=0 (NHWC everywhere)
