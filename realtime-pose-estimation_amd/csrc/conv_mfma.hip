@@ -365,11 +365,12 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
   }
   p.mt = (g.cout % 48 == 0 || g.cout < 48) ? 3 : 4;
   if (g.cout <= 32) p.mt = (g.cout + 15) / 16;
-  // the stride-2 3x3 transition 256 -> 96 (pose_higher_hrnet.py:571-581): its workgroups spend their time staging
-  // (33 x 17)-pixel halo tiles of 4 channel chunks; all 96 output channels in one workgroup stage them once
-  // instead of once per 48-channel block
+  // stride-2 3x3 convs with >= 96 input channels (the 256 -> 96 transition, pose_higher_hrnet.py:571-581, and the
+  // downsampling convs of the fuse layers :213-230): their workgroups spend their time staging (33 x 17)-pixel halo
+  // tiles of 2-4 channel chunks; 96 output channels per workgroup stage them once instead of once per 48-channel
+  // block (256 -> 96: 577 -> 368 us; 96 -> 192: 85 -> 63 us; 192 -> 384: 123 -> 99 us)
   static const int wide = env_int("RTPE_CONV_MT6", 1);
-  if (wide && !dc && g.stride == 2 && g.ksize == 3 && (g.esize == 0 || g.esize == 2) && g.cout == 96 && g.cin >= 128)
+  if (wide && !dc && g.stride == 2 && g.ksize == 3 && (g.esize == 0 || g.esize == 2) && g.cout % 96 == 0 && g.cin >= 96)
     p.mt = 6;
   p.cout_pad = round_up(g.cout, 16 * p.mt);
   p.n_cb = p.cout_pad / (16 * p.mt);
