@@ -94,14 +94,21 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   const int r = lane & 15;
   const int g = lane >> 4;
 
-  // block -> (image, tile row, tile col), cout block
-  uint32_t t = blockIdx.x;
+  // block -> (image, tile row, tile col), cout block.  Workgroups are dealt to the 8 XCDs round robin
+  // (blockIdx.x % 8): the n_cb cout blocks of one tile take consecutive slots of ONE XCD, so they run at the same
+  // time and share the tile's input through that XCD's L2.  (With the cout block as the slow grid dimension every
+  // block of a layer re-read the whole input from HBM: 755 MB fetched per launch of the 64 -> 256 1x1 convs of
+  // layer1 instead of 440 MB, PMC FETCH_SIZE.)
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t tq = slot / (uint32_t)a.n_cb;
+  uint32_t t = tq * 8u + xcd;
+  if (t >= (uint32_t)a.N * (uint32_t)(a.tiles_x * a.tiles_y)) return;      // grid padding (whole workgroup)
   const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
   const uint32_t n = fdiv(t, a.div_tiles_xy);
   t -= n * tiles_xy;
   const uint32_t tyi = fdiv(t, a.div_tiles_x);
   const uint32_t txi = t - tyi * a.tiles_x;
-  const int cb = blockIdx.y;
+  const int cb = (int)(slot - tq * (uint32_t)a.n_cb);
   const int py0 = tyi * a.th, px0 = txi * a.tw;
   const int iy0 = py0 * a.in_mul + a.lo_y, ix0 = px0 * a.in_mul + a.lo_x;
 
@@ -609,7 +616,8 @@ static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStr
     RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
-  dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y), (unsigned)n_cb);
+  const unsigned n_tiles = (unsigned)(a.N * a.tiles_x * a.tiles_y);
+  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb);          // (tile / 8, cout block, tile % 8 = XCD)
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), t.lds_bytes, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;
