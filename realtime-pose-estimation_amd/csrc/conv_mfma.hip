@@ -99,18 +99,28 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   // time and share the tile's input through that XCD's L2.  (With the cout block as the slow grid dimension every
   // block of a layer re-read the whole input from HBM: 755 MB fetched per launch of the 64 -> 256 1x1 convs of
   // layer1 instead of 440 MB, PMC FETCH_SIZE.)
+  // A transposed conv runs its 4 sub-pixel classes in ONE grid (n_cls = 4) as further "blocks" of a tile: their
+  // workgroups write interleaved 96-byte pieces of the same output lines at the same time on one XCD, so the
+  // pieces meet in that L2 and HBM sees whole lines (4 separate launches: 1.5 GB of traffic per deconv for 0.46 GB
+  // of tensors - every partial line was read back - PMC), and they share the input tile.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t tq = slot / (uint32_t)a.n_cb;
+  const uint32_t per_tile = (uint32_t)a.n_cb * (uint32_t)(a.n_cls > 0 ? a.n_cls : 1);
+  const uint32_t tq = slot / per_tile;
   uint32_t t = tq * 8u + xcd;
   if (t >= (uint32_t)a.N * (uint32_t)(a.tiles_x * a.tiles_y)) return;      // grid padding (whole workgroup)
+  const uint32_t sub = slot - tq * per_tile;
+  const int cls = (int)(sub / (uint32_t)a.n_cb);
+  const _Float16* const w_base = a.n_cls > 0 ? a.w_c[cls] : a.w;
+  const int lo_y = a.n_cls > 0 ? a.lo_yc[cls] : a.lo_y, lo_x = a.n_cls > 0 ? a.lo_xc[cls] : a.lo_x;
+  const int oy_add = a.n_cls > 0 ? a.oy_c[cls] : a.oy_add, ox_add = a.n_cls > 0 ? a.ox_c[cls] : a.ox_add;
   const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
   const uint32_t n = fdiv(t, a.div_tiles_xy);
   t -= n * tiles_xy;
   const uint32_t tyi = fdiv(t, a.div_tiles_x);
   const uint32_t txi = t - tyi * a.tiles_x;
-  const int cb = (int)(slot - tq * (uint32_t)a.n_cb);
+  const int cb = (int)(sub - (uint32_t)cls * (uint32_t)a.n_cb);
   const int py0 = tyi * a.th, px0 = txi * a.tw;
-  const int iy0 = py0 * a.in_mul + a.lo_y, ix0 = px0 * a.in_mul + a.lo_x;
+  const int iy0 = py0 * a.in_mul + lo_y, ix0 = px0 * a.in_mul + lo_x;
 
   // LDS byte offset of (tap, channel) for every (k chunk, lane group)
   const int kvalid = a.ntaps * a.cc;
@@ -141,7 +151,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
 
   const int n_k = a.n_cchunks * a.kc;  // total k chunks
-  const uint4* wfrag = reinterpret_cast<const uint4*>(a.w) + (size_t)cb * n_k * MT * 64 + lane;
+  const uint4* wfrag = reinterpret_cast<const uint4*>(w_base) + (size_t)cb * n_k * MT * 64 + lane;
 
   uint4 a_cur[MT];
 #pragma unroll
@@ -172,7 +182,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       const int ch = cb * MT * 16 + slot * EPS;
       rpre[it] = uint4{0u, 0u, 0u, 0u};
       if (c < NT * 16 * CHG && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
-        const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+        const int oy = py * a.o_mul + oy_add, ox = px * a.o_mul + ox_add;
         const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
         rpre[it] = *reinterpret_cast<const uint4*>(rin + pix * a.res_ld + ch);
       }
@@ -284,7 +294,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const uint32_t oxt = p - oyt * a.tw;
         const int py = py0 + (int)oyt, px = px0 + (int)oxt;
         if (py < a.H_pos && px < a.W_pos) {
-          const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+          const int oy = py * a.o_mul + oy_add, ox = px * a.o_mul + ox_add;
           const int c4 = (cb * MT + m) * 16 + g * 4;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -317,7 +327,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       const int py = py0 + (int)oyt, px = px0 + (int)oxt;
       const int ch = cblk + slot * EPS;
       if (py >= a.H_pos || px >= a.W_pos || ch >= a.cout_store) continue;
-      const int oy = py * a.o_mul + a.oy_add, ox = px * a.o_mul + a.ox_add;
+      const int oy = py * a.o_mul + oy_add, ox = px * a.o_mul + ox_add;
       const size_t pix = ((size_t)n * a.H_full + oy) * a.W_full + ox;
       uint4 raw = *reinterpret_cast<const uint4*>(obuf + pw * ROWB + slot * 16);
       T v[EPS];
@@ -617,7 +627,7 @@ static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStr
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   const unsigned n_tiles = (unsigned)(a.N * a.tiles_x * a.tiles_y);
-  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb);          // (tile / 8, cout block, tile % 8 = XCD)
+  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb * (unsigned)(a.n_cls > 0 ? a.n_cls : 1));   // (tile / 8, class, cout block, tile % 8 = XCD)
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), t.lds_bytes, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;

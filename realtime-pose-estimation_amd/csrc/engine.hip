@@ -437,6 +437,9 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
       const bool dc = d.kind == RTPE_OP_DECONV;
       const int Ho = dc ? Hi * 2 : Hi / d.stride, Wo = dc ? Wi * 2 : Wi / d.stride;
+      ConvArgs merged;
+      ConvTile merged_tile;
+      static const int merge_deconv = env_int("RTPE_DECONV_MERGE", 1);
       for (int k = 0; k < o.n_geom && rc == RTPE_OK; ++k) {
         if (only_k >= 0 && k != only_k) continue;
         ConvArgs a;
@@ -483,11 +486,27 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         ConvTile tile;
         if (force)
           tile = *force;
-        else if (tuned && (*tuned)[i * 4 + k].nt)
-          tile = (*tuned)[i * 4 + k];
+        else if (tuned && (*tuned)[i * 4 + (dc && only_k < 0 && merge_deconv ? 0 : k)].nt)
+          tile = (*tuned)[i * 4 + (dc && only_k < 0 && merge_deconv ? 0 : k)];
         else
           tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
+        if (dc && only_k < 0 && merge_deconv && tile.kind != 2) {
+          // the 4 sub-pixel classes as ONE grid (conv_mfma.hip): class k's weights and offsets go into the
+          // argument block of class 0; the launch happens after the last class.  All classes use class 0's
+          // launch shape (their plans differ in the tap offsets and the packed weights only).
+          if (k == 0) { merged = a; merged_tile = tile; merged.n_cls = 4; }
+          merged.w_c[k] = a.w;
+          merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
+          merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
+          const ConvPlan &p0 = o.plan[0], &pk = o.plan[k];
+          if (pk.mt != p0.mt || pk.cc != p0.cc || pk.kc != p0.kc || pk.n_cchunks != p0.n_cchunks || pk.n_cb != p0.n_cb ||
+              pk.pstride != p0.pstride || pk.tapw != p0.tapw || tile.kind == 2) {
+            set_error("forward: the classes of a transposed conv have different plans"); return RTPE_E_INVALID;
+          }
+          if (k == 3) rc = conv_launch(o.plan[0], merged_tile, merged, s);
+          continue;
+        }
         rc = conv_launch(o.plan[k], tile, a, s);
       }
     } else if (d.kind == RTPE_OP_AUX_PACK) {
@@ -748,6 +767,9 @@ extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RTPE_OK;
   std::vector<char*> dev_bufs;
+  ConvArgs merged;
+  ConvTile merged_tile;
+  ConvPlan merged_plan;
   for (int k = 0; k < 4 && rc == RTPE_OK; ++k) {         // the four sub-pixel (parity) classes of the output
     ConvGeom g{cin, cout, 4, 2, k, 2, 1};
     ConvPlan p = conv_make_plan(g);
@@ -776,6 +798,16 @@ extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_
     a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
     const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos);
     conv_fill_args(g, p, tile, &a);
+    // as in the forward: the four classes in one grid (RTPE_DECONV_MERGE=0: four launches)
+    static const int merge_deconv = env_int("RTPE_DECONV_MERGE", 1);
+    if (merge_deconv && tile.kind != 2) {
+      if (k == 0) { merged = a; merged_tile = tile; merged_plan = p; merged.n_cls = 4; }
+      merged.w_c[k] = a.w;
+      merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
+      merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
+      if (k == 3) rc = conv_launch(merged_plan, merged_tile, merged, s);
+      continue;
+    }
     rc = conv_launch(p, tile, a, s);
   }
   hipError_t es = hipStreamSynchronize(s);

@@ -127,6 +127,11 @@ struct ConvArgs {
   FastDiv div_tw, div_slots, div_rowslots, div_cc, div_tiles_x, div_tiles_xy;
   size_t x_bytes;        // bytes from x to the end of its tensor (buffer bounds of the LDS-DMA path)
   int n_cb;              // cout blocks
+  // several sub-launches in ONE grid (one-workgroup-per-tile kernel): the 4 sub-pixel classes of the transposed
+  // conv.  Class c uses w_c[c], lo_yc/lo_xc[c], oy_c/ox_c[c]; everything else is common.  0 = a plain launch
+  int n_cls;
+  const _Float16* w_c[4];
+  int lo_yc[4], lo_xc[4], oy_c[4], ox_c[4];
   int buf_bytes;         // streaming kernel: bytes of one LDS tile buffer
   int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
   int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
