@@ -648,7 +648,10 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     if (p.mt == 6 && c.nt != 2) continue;
     const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                          ((double)H_pos * W_pos);
-    if (waste > 1.35 * min_waste) continue;
+    // (small maps - 20 x 20 at /32 - fit one 20 x 20 tile per image: 32 workgroups for 256 CUs.  Smaller tiles
+    // that pad the map by up to 2.6x are timed as well when the tight tiling cannot fill the chip.)
+    const long wgs_tight = (long)N * p.n_cb * (long)(min_waste * H_pos * W_pos / 400.0 + 0.5);   // ~ workgroups of a 400-px tiling
+    if (waste > (wgs_tight < 256 ? 2.6 : 1.35) * min_waste) continue;
     ConvTile t;
     memset(&t, 0, sizeof(t));
     t.nt = c.nt; t.waves = c.waves; t.th = c.th; t.tw = c.tw;
