@@ -479,6 +479,7 @@ static const TileCand kCands[] = {
     {4, 8, 16, 32}, {4, 8, 32, 16}, {4, 4, 16, 16}, {4, 4, 8, 32}, {4, 4, 32, 8},
     {4, 2, 8, 16},  {4, 2, 16, 8},  {5, 5, 20, 20}, {5, 5, 10, 40}, {5, 5, 40, 10},
     {4, 5, 16, 20}, {4, 5, 20, 16}, {4, 5, 8, 40},  {4, 5, 40, 8},
+    {4, 1, 8, 8},                                    // stride-2 convs: a 17 x 17 halo tile, 2-3 workgroups per CU
 };
 
 static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
@@ -561,7 +562,8 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   memset(&best, 0, sizeof(best));
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;  // 128 accumulators + operands: keep 2 waves/SIMD
-    if (p.mt == 6 && c.nt != 2) continue;  // the 96-cout variant exists for 2 pixel tiles per wave
+    if (p.mt == 6 && c.nt > 2) continue;   // the 96-cout variant exists for 1 and 2 pixel tiles per wave
+    if (c.nt == 1) continue;               // 8 x 8 tiles are autotuning candidates of stride-2 convs only
     if (force_nt && c.nt != force_nt) continue;
     if (force_waves && c.waves != force_waves) continue;
     const size_t lds = tile_lds(p, c.th, c.tw, c.waves, c.nt);
@@ -639,13 +641,15 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
   out->clear();
   double min_waste = 1e30;
   for (const TileCand& c : kCands) {
+    if (c.nt == 1 && (p.in_mul != 2 || p.mt < 3)) continue;
     const double w = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                      ((double)H_pos * W_pos);
     if (w < min_waste) min_waste = w;
   }
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;
-    if (p.mt == 6 && c.nt != 2) continue;
+    if (p.mt == 6 && c.nt > 2) continue;
+    if (c.nt == 1 && (p.in_mul != 2 || p.mt < 3)) continue;
     const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                          ((double)H_pos * W_pos);
     // (small maps - 20 x 20 at /32 - fit one 20 x 20 tile per image: 32 workgroups for 256 CUs.  Smaller tiles
@@ -691,7 +695,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv)                                            \
     return p.esize == 4 ? launch_variant<float, MTv, NTv, Wv>(t, a, p.n_cb, s)                 \
                         : launch_variant<_Float16, MTv, NTv, Wv>(t, a, p.n_cb, s);
-  RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5)
+  RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5) RTPE_V(3, 1, 4) RTPE_V(4, 1, 4) RTPE_V(6, 1, 4)
   RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5) RTPE_V(6, 2, 4)
   RTPE_V(2, 8, 4) RTPE_V(2, 4, 4) RTPE_V(2, 2, 4) RTPE_V(2, 5, 4) RTPE_V(2, 5, 5)
   RTPE_V(1, 8, 4) RTPE_V(1, 4, 4) RTPE_V(1, 2, 4) RTPE_V(1, 5, 4) RTPE_V(1, 5, 5)
