@@ -91,19 +91,67 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
   const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < 27 * kStemCO; i += 256) wl[i / kStemCO][i % kStemCO] = (float)reinterpret_cast<const T*>(a.w)[i];
-  for (int i = tid; i < 3 * kStemPH * kStemPW; i += 256) {
-    const int c = i / (kStemPH * kStemPW);
-    const int rem = i - c * kStemPH * kStemPW;
-    const int py = rem / kStemPW, px = rem - py * kStemPW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-      const size_t o = (((size_t)n * 3 + c) * a.H + iy) * a.W + ix;
-      v = a.x_f32 ? reinterpret_cast<const float*>(a.x)[o] : (float)reinterpret_cast<const _Float16*>(a.x)[o];
-      if (kHalf) v = round16(v);                          // tofp16 of the half wrapper
+  // Staging: ALL global loads of a thread are issued before the first LDS write.  (The plain loops compiled to one
+  // load + s_waitcnt vmcnt(0) per iteration: ~20 dependent memory round trips per workgroup, which - not the
+  // 864 packed FMAs per thread - set the kernel's time: 2 TB/s, 4x its VALU floor.)
+  {
+    float* wflat = &wl[0][0];
+    uint4v wq[2];
+    constexpr int kWVec = kHalf ? 27 * kStemCO / 8 : 27 * kStemCO / 4;    // 16-byte pieces of the weights: 216 / 432
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + k * 256 < kWVec) wq[k] = reinterpret_cast<const uint4v*>(a.w)[tid + k * 256];
+    constexpr int kPatch = 3 * kStemPH * kStemPW, kIter = (kPatch + 255) / 256;
+    auto locate = [&](int k, int* dst, bool* ok, int* src) __attribute__((always_inline)) {
+      const int i = tid + k * 256;
+      const int c = i < kPatch ? i / (kStemPH * kStemPW) : 0;
+      const int rem = i < kPatch ? i - c * kStemPH * kStemPW : 0;
+      const int py = rem / kStemPW, px = rem - py * kStemPW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      *dst = i < kPatch ? (c * kStemPH + py) * (kStemPW + 1) + px : -1;
+      *ok = i < kPatch && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      // (no branch around the load: an element outside the image reads a clamped pixel and is zeroed below)
+      const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      *src = ((n * 3 + c) * a.H + cy) * a.W + cx;             // < 2^31 elements (host-checked)
+    };
+    float v[kIter];
+    if (a.x_f32) {
+#pragma unroll
+      for (int k = 0; k < kIter; ++k) {
+        int dst, src; bool ok;
+        locate(k, &dst, &ok, &src);
+        v[k] = reinterpret_cast<const float*>(a.x)[src];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kIter; ++k) {
+        int dst, src; bool ok;
+        locate(k, &dst, &ok, &src);
+        v[k] = (float)reinterpret_cast<const _Float16*>(a.x)[src];
+      }
     }
-    patch[c][py][px] = v;
+    if (kHalf) {                                          // 27 * 64 fp16 = 216 x 16 bytes
+      if (tid < kWVec) {
+        const _Float16* h = reinterpret_cast<const _Float16*>(&wq[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wflat[tid * 8 + j] = (float)h[j];
+      }
+    } else {                                              // 27 * 64 fp32 = 432 x 16 bytes
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (tid + k * 256 < kWVec) reinterpret_cast<uint4v*>(wflat)[tid + k * 256] = wq[k];
+    }
+    float* pflat = &patch[0][0][0];
+#pragma unroll
+    for (int k = 0; k < kIter; ++k) {
+      int dst, src; bool ok;
+      int tid_l = tid;
+      asm volatile("" : "+v"(tid_l));                     // recompute the positions: 13 x 3 registers are not worth holding
+      (void)tid_l;
+      locate(k, &dst, &ok, &src);
+      const float x = ok ? v[k] : 0.f;
+      if (dst >= 0) pflat[dst] = kHalf ? round16(x) : x;    // tofp16 of the half wrapper
+    }
   }
   __syncthreads();
 
@@ -177,6 +225,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
 
 int stem_launch(const StemArgs& a, hipStream_t s) {
   RTPE_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0 && a.out_ld % 8 == 0, "stem: H=%d W=%d", a.H, a.W);
+  RTPE_REQUIRE((size_t)a.N * 3 * a.H * a.W < 0x7fffffffull, "stem: input of %d x 3 x %d x %d elements", a.N, a.H, a.W);
   const int Ho = a.H / 2, Wo = a.W / 2;
   const int tiles = ((Wo + kStemTW - 1) / kStemTW) * ((Ho + kStemTH - 1) / kStemTH);
   if (a.f32)
