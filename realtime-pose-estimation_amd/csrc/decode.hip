@@ -179,11 +179,25 @@ __device__ __forceinline__ bool fill_raw<BilinearMap>(const BilinearMap& m, int 
   const bool staged = stage != nullptr && ky0 <= ky1 && kx0 <= kx1 && er > 0 && ec > 0 && er * ec <= stage_floats;
   if (staged) {
     bool pos = false;
-    for (int i = threadIdx.x; i < er * ec; i += 256) {
-      const int r = i / ec, c = i - r * ec;
-      const float v = b[(sr0 + r) * m.sw + sc0 + c];
-      stage[i] = v;
-      pos |= v > 0.f;
+    // four loads in flight per thread before the first LDS write (the plain loop compiled to one load + vmcnt(0) per
+    // element: one memory round trip per 256 source values; a tile has ~700)
+    for (int i0 = threadIdx.x; i0 < er * ec; i0 += 4 * 256) {
+      float v4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 256;
+        const int ii = i < er * ec ? i : 0;               // (no branch around the load)
+        const int r = ii / ec, c = ii - r * ec;
+        v4[k] = b[(sr0 + r) * m.sw + sc0 + c];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 256;
+        if (i < er * ec) {
+          stage[i] = v4[k];
+          pos |= v4[k] > 0.f;
+        }
+      }
     }
     if (pos_flag != nullptr && pos) *pos_flag = 1;         // (the caller zeroed it before the axis-table barrier)
     __syncthreads();
