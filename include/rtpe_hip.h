@@ -205,8 +205,10 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Process-wide tuning options; every setting gives bit-identical results (they select between kernel
- * variants for A/B measurements in one process).  "block_ring" = 1: the fused BasicBlock kernel streams its
- * weights through a 3-slot LDS ring instead of keeping them resident (default 0; env RTPE_BLOCK_RING). */
+ * variants for A/B measurements in one process).  "block_pc" = 0: the fused BasicBlock never runs on the
+ * producer / consumer kernel (default 1: wherever H % 8 == 0 and W % 16 == 0; env RTPE_BLOCK_PC).  "block_ring" = 1:
+ * the fused BasicBlock kernel streams its weights through a 3-slot LDS ring instead of keeping them resident
+ * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc"). */
 int rtpe_set_option(const char* name, int32_t value);
 
 /* rtpe_hrnet_forward for a program with a second input (RTPE_OP_AUX_PACK): aux = (N,3,H,W) fp32 NCHW on the
