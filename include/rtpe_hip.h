@@ -210,6 +210,9 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
  * the fused BasicBlock kernel streams its weights through a 3-slot LDS ring instead of keeping them resident
  * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc"). */
 int rtpe_set_option(const char* name, int32_t value);
+/* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
+ * launch will use.  bench.py names the kernel it reports from this, not from the environment. */
+int rtpe_get_option(const char* name, int32_t* value);
 
 /* rtpe_hrnet_forward for a program with a second input (RTPE_OP_AUX_PACK): aux = (N,3,H,W) fp32 NCHW on the
  * device (AttentionStudentSteps.forward(x, alt=...), students.py:966).  Everything else as rtpe_hrnet_forward. */

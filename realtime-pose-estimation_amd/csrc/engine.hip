@@ -87,6 +87,17 @@ extern "C" int rtpe_set_option(const char* name, int32_t value) {
   return RTPE_E_INVALID;
 }
 
+extern "C" int rtpe_get_option(const char* name, int32_t* value) {
+  RTPE_REQUIRE(name != nullptr && value != nullptr, "get_option: null argument");
+  for (int k = 0; k < kNumOptions; ++k)
+    if (kOptionNames[k][0] && strcmp(name, kOptionNames[k]) == 0) {
+      *value = get_option(k);
+      return RTPE_OK;
+    }
+  set_error("get_option: unknown option '%s'", name);
+  return RTPE_E_INVALID;
+}
+
 extern "C" const char* rtpe_last_error_string(void) { return g_err.c_str(); }
 extern "C" int rtpe_version(void) { return 1; }
 extern "C" int rtpe_device_count(void) {
@@ -439,7 +450,26 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       const int Ho = dc ? Hi * 2 : Hi / d.stride, Wo = dc ? Wi * 2 : Wi / d.stride;
       ConvArgs merged;
       ConvTile merged_tile;
+      memset(&merged, 0, sizeof(merged));
+      memset(&merged_tile, 0, sizeof(merged_tile));
       static const int merge_deconv = env_int("RTPE_DECONV_MERGE", 1);
+      // the 4 sub-pixel classes of a transposed conv run as ONE grid (conv_mfma.hip) on class 0's launch shape
+      // when that shape is a one-workgroup-per-tile one and the plans of all classes agree (they differ in the
+      // tap offsets and the packed weights only): decided once, before any class is set up
+      ConvTile tile0;
+      memset(&tile0, 0, sizeof(tile0));
+      bool merge = false;
+      if (dc && only_k < 0 && merge_deconv) {
+        if (force) tile0 = *force;
+        else if (tuned && (*tuned)[i * 4].nt) tile0 = (*tuned)[i * 4];
+        else tile0 = conv_make_tile(o.plan[0], N, Hi, Wi);
+        merge = tile0.kind != 2;
+        for (int k = 1; k < o.n_geom && merge; ++k) {
+          const ConvPlan &p0 = o.plan[0], &pk = o.plan[k];
+          merge = pk.mt == p0.mt && pk.cc == p0.cc && pk.kc == p0.kc && pk.n_cchunks == p0.n_cchunks &&
+                  pk.n_cb == p0.n_cb && pk.pstride == p0.pstride && pk.tapw == p0.tapw;
+        }
+      }
       for (int k = 0; k < o.n_geom && rc == RTPE_OK; ++k) {
         if (only_k >= 0 && k != only_k) continue;
         ConvArgs a;
@@ -484,27 +514,22 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         a.relu = (d.flags & RTPE_F_RELU) ? 1 : 0;
         a.round_conv = (d.flags & RTPE_F_ROUND_CONV) ? 1 : 0;
         ConvTile tile;
-        if (force)
+        if (merge)
+          tile = tile0;
+        else if (force)
           tile = *force;
-        else if (tuned && (*tuned)[i * 4 + (dc && only_k < 0 && merge_deconv ? 0 : k)].nt)
-          tile = (*tuned)[i * 4 + (dc && only_k < 0 && merge_deconv ? 0 : k)];
+        else if (tuned && (*tuned)[i * 4 + k].nt)
+          tile = (*tuned)[i * 4 + k];
         else
           tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
-        if (dc && only_k < 0 && merge_deconv && tile.kind != 2) {
-          // the 4 sub-pixel classes as ONE grid (conv_mfma.hip): class k's weights and offsets go into the
-          // argument block of class 0; the launch happens after the last class.  All classes use class 0's
-          // launch shape (their plans differ in the tap offsets and the packed weights only).
+        if (merge) {
+          // class k's weights and offsets go into the argument block of class 0; the launch follows the last class
           if (k == 0) { merged = a; merged_tile = tile; merged.n_cls = 4; }
           merged.w_c[k] = a.w;
           merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
           merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
-          const ConvPlan &p0 = o.plan[0], &pk = o.plan[k];
-          if (pk.mt != p0.mt || pk.cc != p0.cc || pk.kc != p0.kc || pk.n_cchunks != p0.n_cchunks || pk.n_cb != p0.n_cb ||
-              pk.pstride != p0.pstride || pk.tapw != p0.tapw || tile.kind == 2) {
-            set_error("forward: the classes of a transposed conv have different plans"); return RTPE_E_INVALID;
-          }
-          if (k == 3) rc = conv_launch(o.plan[0], merged_tile, merged, s);
+          if (k == o.n_geom - 1) rc = conv_launch(o.plan[0], merged_tile, merged, s);
           continue;
         }
         rc = conv_launch(o.plan[k], tile, a, s);
@@ -769,10 +794,22 @@ extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_
   std::vector<char*> dev_bufs;
   ConvArgs merged;
   ConvTile merged_tile;
-  ConvPlan merged_plan;
+  memset(&merged, 0, sizeof(merged));
+  memset(&merged_tile, 0, sizeof(merged_tile));
+  // as in the forward: the four classes in one grid on class 0's launch shape when that is a one-workgroup-per-
+  // tile shape and all plans agree (RTPE_DECONV_MERGE=0: four launches); decided before any class is set up
+  static const int merge_deconv = env_int("RTPE_DECONV_MERGE", 1);
+  ConvPlan plans[4];
+  for (int k = 0; k < 4; ++k) plans[k] = conv_make_plan(ConvGeom{cin, cout, 4, 2, k, 2, 1});
+  const ConvTile tile0 = conv_make_tile(plans[0], N, H, W);
+  bool merge = merge_deconv && tile0.kind != 2;
+  for (int k = 1; k < 4 && merge; ++k)
+    merge = plans[k].mt == plans[0].mt && plans[k].cc == plans[0].cc && plans[k].kc == plans[0].kc &&
+            plans[k].n_cchunks == plans[0].n_cchunks && plans[k].n_cb == plans[0].n_cb &&
+            plans[k].pstride == plans[0].pstride && plans[k].tapw == plans[0].tapw;
   for (int k = 0; k < 4 && rc == RTPE_OK; ++k) {         // the four sub-pixel (parity) classes of the output
     ConvGeom g{cin, cout, 4, 2, k, 2, 1};
-    ConvPlan p = conv_make_plan(g);
+    const ConvPlan p = plans[k];
     std::vector<char> packed(p.packed_bytes);
     conv_pack_weights(g, p, w_host, packed.data());
     std::vector<float> ab(2 * p.cout_pad, 0.f);
@@ -796,16 +833,14 @@ extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_
     a.H_pos = H; a.W_pos = W; a.o_mul = 2; a.oy_add = k >> 1; a.ox_add = k & 1;
     a.relu = (flags & RTPE_F_RELU) ? 1 : 0;
     a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
-    const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos);
+    const ConvTile tile = merge ? tile0 : conv_make_tile(p, N, a.H_pos, a.W_pos);
     conv_fill_args(g, p, tile, &a);
-    // as in the forward: the four classes in one grid (RTPE_DECONV_MERGE=0: four launches)
-    static const int merge_deconv = env_int("RTPE_DECONV_MERGE", 1);
-    if (merge_deconv && tile.kind != 2) {
-      if (k == 0) { merged = a; merged_tile = tile; merged_plan = p; merged.n_cls = 4; }
+    if (merge) {
+      if (k == 0) { merged = a; merged_tile = tile; merged.n_cls = 4; }
       merged.w_c[k] = a.w;
       merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
       merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
-      if (k == 3) rc = conv_launch(merged_plan, merged_tile, merged, s);
+      if (k == 3) rc = conv_launch(plans[0], merged_tile, merged, s);
       continue;
     }
     rc = conv_launch(p, tile, a, s);

@@ -176,29 +176,35 @@ class TeacherPipeline:
                     t.record_stream(side)
                 return fn(*args)
 
-        with torch.no_grad():
-            for k, x in enumerate(batches):
-                preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
-                hw = tuple(out_hw) if out_hw is not None else tuple(x.shape[2:])
-                f_done = None
-                if side is not None:
-                    f_done = torch.cuda.Event()
-                    f_done.record(main)
+        # ``on_forward`` must return FRESH output tensors for every batch (the plain forward does): the decode of
+        # batch k runs on the side stream while F(k+1) runs on the main one, and nothing makes F(k+1) wait for it.
+        try:
+            with torch.no_grad():
+                for k, x in enumerate(batches):
+                    preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
+                    hw = tuple(out_hw) if out_hw is not None else tuple(x.shape[2:])
+                    f_done = None
+                    if side is not None:
+                        f_done = torch.cuda.Event()
+                        f_done.record(main)
+                    if topk_done is not None:
+                        on_decode_stream(P.lowres_match, topk_done)     # host matching overlaps F(k) on the GPU
+                    st = on_decode_stream(P.lowres_topk, refined, preds[:, NUM_HEATMAPS:], hw, after=f_done,
+                                          uses=(preds, refined))
+                    if refine_done is not None:
+                        yield P.lowres_finish(refine_done)
+                    refine_done, topk_done = topk_done, st
                 if topk_done is not None:
-                    on_decode_stream(P.lowres_match, topk_done)     # host matching overlaps F(k) on the GPU
-                st = on_decode_stream(P.lowres_topk, refined, preds[:, NUM_HEATMAPS:], hw, after=f_done,
-                                      uses=(preds, refined))
+                    on_decode_stream(P.lowres_match, topk_done)
                 if refine_done is not None:
                     yield P.lowres_finish(refine_done)
-                refine_done, topk_done = topk_done, st
-            if topk_done is not None:
-                on_decode_stream(P.lowres_match, topk_done)
-            if refine_done is not None:
-                yield P.lowres_finish(refine_done)
-            if topk_done is not None:
-                yield P.lowres_finish(topk_done)
+                if topk_done is not None:
+                    yield P.lowres_finish(topk_done)
+        finally:
+            # also when the consumer stops early or an exception propagates: whoever continues on the main stream
+            # sees the decode as done
             if side is not None:
-                main.wait_stream(side)          # whoever continues on the main stream sees the decode as done
+                main.wait_stream(side)
 
     def gather(self, image_ids, results, equal_counts=False):
         """all-gather of the decoded keypoints over the process group (RCCL).  ``equal_counts``:

@@ -117,11 +117,17 @@ def aggregate_results(scale_factor, final_heatmaps, tags_list, heatmaps, tags, s
 
 
 def multi_scale_inference(model, parser, image, input_size=640, scale_factors=(1,), flip_test=True,
-                          project2image=True, adjust=True, refine=True, device="cuda", **stage_kw):
+                          project2image=True, adjust=True, refine=True, device="cuda", ags=False, **stage_kw):
     """The per-image body of legacy/valid_ae1dim.py:166-207: for every test scale (largest first) warp the image,
     run the teacher (and its mirror image), aggregate; average the heat maps over the scales, concatenate the tag
     maps, group with ``parser.parse`` and map the keypoints back to image coordinates with ``get_final_preds``.
-    image: (h, w, 3) uint8.  Returns ``(final_results, scores, final_heatmaps, tags)``."""
+    image: (h, w, 3) uint8.  Returns ``(final_results, scores, final_heatmaps, tags)``.
+
+    ``ags=True`` takes the branch the reference script actually runs (valid_ae1dim.py:177, :191-199, ``AGS = True``):
+    the grouping sees ONE tag map for all joints - channel 0 of the first (un-mirrored) tag map of the LAST scale of
+    the loop, a (1,1,h,w,1) tensor - with ``parser.tag_per_joint = False`` (the script sets the attribute on the
+    caller's parser and leaves it set; so does this) and ``adjust = refine = True`` whatever the arguments say.
+    ``tags`` in the result is then that tensor."""
     from .third_party import transforms
     scale_factors = list(scale_factors)
     base_size, center, scale = transforms.get_multi_scale_size(image, input_size, 1.0, min(scale_factors))
@@ -130,12 +136,18 @@ def multi_scale_inference(model, parser, image, input_size=640, scale_factors=(1
         for s in sorted(scale_factors, reverse=True):
             t, center, scale = transforms.warp_normalize(image, input_size, s, min(scale_factors), device=device)
             _, heatmaps, tags = get_multi_stage_outputs(model, t, flip_test, project2image, base_size, **stage_kw)
+            ags_map = tags[0][:, 0].unsqueeze(-1).unsqueeze(0)          # valid_ae1dim.py:177
             final_heatmaps, tags_list = aggregate_results(s, final_heatmaps, tags_list, heatmaps, tags, scale_factors,
                                                           flip_test, project2image)
         if len(scale_factors) != 1:
             final_heatmaps = resize_combine(final_heatmaps, final_heatmaps.shape[2:], div=float(len(scale_factors)))
         tags = torch.cat(tags_list, dim=4)
-        grouped, scores = parser.parse(final_heatmaps, tags, adjust, refine)
+        if ags:
+            parser.tag_per_joint = False                                # valid_ae1dim.py:196
+            tags = ags_map.contiguous()
+            grouped, scores = parser.parse(final_heatmaps, tags, True, True)
+        else:
+            grouped, scores = parser.parse(final_heatmaps, tags, adjust, refine)
     final_results = transforms.get_final_preds(grouped, center, scale,
                                                [final_heatmaps.size(3), final_heatmaps.size(2)])
     return final_results, scores, final_heatmaps, tags

@@ -120,6 +120,55 @@ def test_conv_layer(nat, case):
     assert same > 0.97, "only %.4f identical" % same
 
 
+@pytest.mark.parametrize("hw,n,f32in", [((64, 96), 2, True), ((160, 224), 3, True), ((32, 32), 1, False), ((96, 352), 2, True)])
+def test_stem_and_nchw_head_epilogues(nat, hw, n, f32in):
+    """layer-level check of the two kernels that touch the NCHW boundary, through the ABI (rtpe_hrnet_create /
+    rtpe_hrnet_forward on a three-op program): the Cin = 3 stem kernel (conv1 + bn1 + ReLU with ``tofp16`` folded
+    in, pose_higher_hrnet.py:363-365 of the reference) and the two head epilogues that write NCHW fp32 straight
+    from the accumulators (``tofp32`` folded in, :447-483; one with 34 and one with 17 output channels, bias, no
+    BN), against the fp16 PyTorch-CPU ops with one rounding after conv, BN and ReLU.  The network tests cover
+    these kernels only inside 330-op programs."""
+    import torch.nn as nn
+    from rtpe.third_party.pose_higher_hrnet import Engine, ProgramBuilder
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 7 + W)
+    conv1, bn1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+    heads = [nn.Conv2d(64, 34, 1, bias=True), nn.Conv2d(64, 17, 1, bias=True)]
+    with torch.no_grad():
+        conv1.weight.copy_((torch.rand(conv1.weight.shape, generator=g) * 2 - 1) / 27 ** 0.5)
+        bn1.weight.copy_(torch.rand(64, generator=g) * 0.4 + 0.8)
+        bn1.bias.copy_(torch.randn(64, generator=g) * 0.1)
+        bn1.running_mean.copy_(torch.randn(64, generator=g) * 0.05)
+        bn1.running_var.copy_(torch.rand(64, generator=g) * 0.2 + 0.9)
+        for hd in heads:
+            hd.weight.copy_((torch.rand(hd.weight.shape, generator=g) * 2 - 1) / 8.0)
+            hd.bias.copy_(torch.randn(hd.out_channels, generator=g) * 0.1)
+    for mod in [conv1] + heads:
+        mod.half()
+    b = ProgramBuilder(f32=False)
+    t = b.stem(conv1, bn1)
+    b.conv(t, heads[0], None, out_flag=nat.F_OUT_PREDS, nhwc=False)
+    b.conv(t, heads[1], None, out_flag=nat.F_OUT_REFINED, nhwc=False)
+    eng = Engine(b.finish(), 0)
+    x = torch.randn(n, 3, H, W, generator=g)
+    xin = x if f32in else x.half()
+    with torch.no_grad():
+        preds, refined = eng.forward(xin.to("cuda:0"), torch.float32)
+        # the reference's ops on the CPU: tofp16, fp16 conv, fp32 BatchNorm on fp16 data, ReLU, fp16 1x1 conv + bias, tofp32
+        y = F.conv2d(x.half(), conv1.weight, None, 2, 1)
+        bn1.float().eval()
+        y = F.relu(bn1(y.float()).half())
+        want = [F.conv2d(y, hd.weight, hd.bias).float() for hd in heads]
+    assert preds.shape == (n, 34, H // 2, W // 2) and refined.shape == (n, 17, H // 2, W // 2) and preds.dtype == torch.float32
+    for name, got, w_ in (("head 34", preds, want[0]), ("head 17", refined, want[1])):
+        gotn, wn = got.cpu().numpy(), w_.numpy()
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(wn), 0.25))) - 10)
+        err = np.abs(gotn - wn) / ulp
+        same = (gotn == wn).mean()
+        print("%dx%d n=%d %s: max %.2f fp16 steps, identical %.4f" % (H, W, n, name, err.max(), same))
+        assert err.max() <= 2.0 and same > 0.97
+
+
 STREAM_CASES = [
     # cin, cout, H, W, N, residual: enough (tile, cout block) units that every persistent workgroup of the
     # streaming kernel walks several of them (halo buffer ring, weight ring, residual sets two units ahead)
@@ -676,6 +725,107 @@ def test_parse_lowres_planes_without_a_positive_maximum(nat):
         np.testing.assert_array_equal(np.array(scores, np.float32), np.array(wsc, np.float32))
 
 
+# ---- the public branches of parse no other fixture takes (decode_branches.npz, made by the reference) ----------
+SWITCHES = ((True, True), (False, True), (True, False), (False, False))
+
+
+def _check_branch(g, key, ans, scores):
+    got_n = np.array([len(a) if getattr(a, "ndim", 0) == 3 else 0 for a in ans], np.int32)
+    np.testing.assert_array_equal(got_n, g[key + "_n"])
+    np.testing.assert_array_equal(np.asarray(ans[0], np.float32), g[key + "_final"])
+    np.testing.assert_array_equal(np.array(scores, np.float32), g[key + "_scores"])
+
+
+@pytest.mark.parametrize("name", ["ags_p4", "ags_p12"])
+def test_parse_with_one_tag_map_for_all_joints(nat, golden_dir, name):
+    """``tag_per_joint=False`` with a (1,1,h,w,1) tag tensor: what the reference's upstream-faithful script runs
+    (legacy/valid_ae1dim.py:177,191-199); top-k tables and all four adjust / refine combinations, bit for bit
+    against the reference's results"""
+    from rtpe.third_party.group import HeatmapParser
+    g = np.load(os.path.join(golden_dir, "decode_branches.npz"))
+    P, h, w, seed = [int(v) for v in g[name + "_meta"]]
+    det, tag = synth.make_decode_maps(P, h, w, seed=seed)
+    ags = np.ascontiguousarray(tag.max(axis=1, keepdims=True))
+    det_d, ags_d = torch.from_numpy(det).to("cuda:0"), torch.from_numpy(ags).to("cuda:0")
+    hp = HeatmapParser(17, 30, 0.1, 1.0, True, False, tag_per_joint=False)
+    tk = hp.top_k(det_d, ags_d)
+    np.testing.assert_array_equal(tk["val_k"], g[name + "_val_k"])
+    live = g[name + "_val_k"] > 0.1
+    np.testing.assert_array_equal(tk["loc_k"][live], g[name + "_loc_k"][live])
+    np.testing.assert_array_equal(tk["tag_k"][live], g[name + "_tag_k"][live])
+    for a, r in SWITCHES:
+        ans, scores = hp.parse(det_d, ags_d, adjust=a, refine=r)
+        _check_branch(g, "%s_a%d_r%d" % (name, a, r), ans, scores)
+    # the attribute is public and callers flip it on a live parser (valid_ae1dim.py:196)
+    hp2 = _parser()
+    hp2.tag_per_joint = False
+    ans, scores = hp2.parse(det_d, ags_d, True, True)
+    _check_branch(g, name + "_a1_r1", ans, scores)
+
+
+@pytest.mark.parametrize("name", ["sw_p6", "sw_p9_d2"])
+def test_parse_with_adjust_or_refine_switched_off(nat, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "decode_branches.npz"))
+    P, h, w, seed, D = [int(v) for v in g[name + "_meta"]]
+    det, tag = synth.make_decode_maps(P, h, w, seed=seed, tag_dim=D)
+    det_d, tag_d = torch.from_numpy(det).to("cuda:0"), torch.from_numpy(tag).to("cuda:0")
+    for a, r in SWITCHES[1:]:
+        ans, scores = _parser().parse(det_d, tag_d, adjust=a, refine=r)
+        _check_branch(g, "%s_a%d_r%d" % (name, a, r), ans, scores)
+
+
+@pytest.mark.parametrize("name", ["lowres_p5", "lowres_p3_nonsq"])
+def test_parse_lowres_with_adjust_or_refine_switched_off(nat, golden_dir, name):
+    """the fused batch entry with the same switches, against the reference's upsample + parse of the same maps"""
+    g = np.load(os.path.join(golden_dir, "decode_branches.npz"))
+    P, H, W, oh, ow, seed = [int(v) for v in g[name + "_meta"]]
+    refined, tags = synth.make_lowres_maps(P, H, W, seed=seed)
+    rd, td = torch.from_numpy(refined).to("cuda:0"), torch.from_numpy(tags).to("cuda:0")
+    for a, r in SWITCHES[1:]:
+        people, scores = _parser().parse_lowres(rd, td, (oh, ow), adjust=a, refine=r)[0]
+        key = "%s_a%d_r%d" % (name, a, r)
+        np.testing.assert_array_equal(people, g[key + "_final"])
+        np.testing.assert_array_equal(np.array(scores, np.float32), g[key + "_scores"])
+
+
+def test_run_sharded_list_on_one_rank(nat, teacher):
+    """configs[3]'s entry point (bench.py --list -> engine.run_sharded_list) on the one GPU a test box has: the
+    100 names of the reference's assets/coco_minival2017_100.txt, batches of 32 with a short last batch (4), every
+    id back exactly once, and the records equal to what the pipeline returns for the same inputs"""
+    from rtpe import engine
+    m, sd = teacher("W0")
+    names = [ln.strip() for ln in open(os.path.join(ROOT, "tests", "golden", "coco_minival2017_100.txt")) if ln.strip()]
+    assert len(names) == 100
+    pipe = engine.TeacherPipeline(m, device="cuda:0")
+    gen = torch.Generator(device="cuda:0")
+    S = 128
+    sizes, kept = [], {}
+
+    def infer(part):
+        xb = torch.empty((len(part), 3, S, S), device="cuda:0")
+        for i, nm in enumerate(part):
+            gen.manual_seed(engine.image_id_of(nm))
+            xb[i] = torch.randn(3, S, S, generator=gen, device="cuda:0")
+        res = pipe(xb, out_hw=(S, S))
+        sizes.append(len(part))
+        for nm, r in zip(part, res):
+            kept[engine.image_id_of(nm)] = r
+        return res
+    out = engine.run_sharded_list(names, infer, 32, torch.device("cuda:0"))
+    assert sizes == [32, 32, 32, 4]
+    assert sorted(out) == sorted(engine.image_id_of(n) for n in names)
+    n_people = 0
+    for img_id, (kp, sc) in out.items():
+        people, scores = kept[img_id]
+        n = min(len(people) if people.ndim == 3 else 0, engine.MAX_PEOPLE_RECORD)
+        assert kp.shape == (n, 17, 4)
+        if n:
+            np.testing.assert_array_equal(kp, people[:n, :, :4])
+            np.testing.assert_array_equal(sc, np.array(scores[:n], np.float32))
+        n_people += n
+    assert n_people > 0
+
+
 def test_end_to_end_pipeline_and_margin_aware_indices(nat, teacher):
     """forward + decode on the GPU vs oracle forward + oracle decode.  Random-weight
     heat maps are noise, so candidates are compared where the CPU and GPU maps
@@ -939,6 +1089,22 @@ def test_multi_scale_flip_inference_end_to_end(nat, teacher):
     if len(want[0]):
         back = transforms.get_final_preds(want, center, scale, [want_hm.size(3), want_hm.size(2)])
         np.testing.assert_allclose(np.stack(final_results), np.stack(back), rtol=0, atol=0)
+    # the branch the reference script takes (valid_ae1dim.py:177,191-199, AGS = True): ONE tag map for all joints -
+    # channel 0 of the un-mirrored tag map of the last (smallest) scale - and parser.tag_per_joint = False
+    parser2 = HeatmapParser(17, 30, 0.1, 1.0, True, False)
+    res_a, sc_a, hm_a, ags = inference.multi_scale_inference(m, parser2, img, 256, scales, True, True, device="cuda:0",
+                                                             ags=True)
+    assert parser2.tag_per_joint is False and tuple(ags.shape) == (1, 1, base_size[1], base_size[0], 1)
+    assert torch.equal(hm_a, final_hm)
+    _, _, tags_last = inference_ref.get_multi_stage_outputs(cpu_model, inputs[min(scales)], True, True, base_size)
+    want_ags = tags_last[0][:, 0].unsqueeze(-1).unsqueeze(0)
+    assert torch.equal(ags.cpu(), want_ags)
+    want_a, wsc_a = decode_ref.HeatmapParserRef(tag_per_joint=False).parse(want_hm, want_ags, True, True)
+    assert len(res_a) == len(want_a[0])
+    np.testing.assert_array_equal(np.array(sc_a, np.float32), np.array(wsc_a, np.float32))
+    if len(want_a[0]):
+        back = transforms.get_final_preds(want_a, center, scale, [want_hm.size(3), want_hm.size(2)])
+        np.testing.assert_allclose(np.stack(res_a), np.stack(back), rtol=0, atol=0)
 
 
 # --------------------------------------------------------------------------- #

@@ -262,3 +262,60 @@ def test_two_bundled_images_match_reference(golden_dir, w48_shapes, name, varian
     np.testing.assert_array_equal(np.concatenate([center, scale]), g[name + "_center_scale"])
     sd = synth.make_state_dict(w48_shapes, 0, variant)
     _check_loop_body(g, "%s_%s_" % (name, variant), _loop_body_oracle(sd, torch.from_numpy(t)[None], h, w))
+
+
+# --------------------------------------------------------------------------- #
+# round 3 fixtures: the decode branches no other fixture takes (tag_per_joint=False = the AGS branch of
+# legacy/valid_ae1dim.py:177,191-199; adjust / refine switched off, group.py:269,274)
+# --------------------------------------------------------------------------- #
+SWITCHES = ((True, True), (False, True), (True, False), (False, False))
+
+
+def _check_branch(g, key, ans, scores):
+    want_n = g[key + "_n"]
+    got_n = np.array([len(a) if getattr(a, "ndim", 0) == 3 else 0 for a in ans], np.int32)
+    np.testing.assert_array_equal(got_n, want_n)
+    np.testing.assert_array_equal(np.asarray(ans[0], np.float32), g[key + "_final"])
+    np.testing.assert_array_equal(np.array(scores, np.float32), g[key + "_scores"])
+
+
+@pytest.mark.parametrize("name", ["ags_p4", "ags_p12"])
+def test_decode_one_tag_map_for_all_joints_matches_reference(golden_dir, name):
+    g = _load(golden_dir, "decode_branches.npz")
+    P, h, w, seed = [int(v) for v in g[name + "_meta"]]
+    det, tag = synth.make_decode_maps(P, h, w, seed=seed)
+    ags = np.ascontiguousarray(tag.max(axis=1, keepdims=True))               # (1,1,h,w,1)
+    det_t, ags_t = torch.from_numpy(det), torch.from_numpy(ags)
+    hp = decode_ref.HeatmapParserRef(tag_per_joint=False)
+    tk = hp.top_k(det_t, ags_t)
+    np.testing.assert_array_equal(tk["val_k"], g[name + "_val_k"])
+    live = g[name + "_val_k"] > 0.1
+    np.testing.assert_array_equal(tk["loc_k"][live], g[name + "_loc_k"][live])
+    np.testing.assert_array_equal(tk["tag_k"][live], g[name + "_tag_k"][live])
+    for a, r in SWITCHES:
+        ans, scores = hp.parse(det_t.clone(), ags_t.clone(), adjust=a, refine=r)
+        _check_branch(g, "%s_a%d_r%d" % (name, a, r), ans, scores)
+
+
+@pytest.mark.parametrize("name", ["sw_p6", "sw_p9_d2"])
+def test_decode_adjust_refine_switches_match_reference(golden_dir, name):
+    g = _load(golden_dir, "decode_branches.npz")
+    P, h, w, seed, D = [int(v) for v in g[name + "_meta"]]
+    det, tag = synth.make_decode_maps(P, h, w, seed=seed, tag_dim=D)
+    hp = decode_ref.HeatmapParserRef()
+    for a, r in SWITCHES[1:]:
+        ans, scores = hp.parse(torch.from_numpy(det.copy()), torch.from_numpy(tag.copy()), adjust=a, refine=r)
+        _check_branch(g, "%s_a%d_r%d" % (name, a, r), ans, scores)
+
+
+@pytest.mark.parametrize("name", ["lowres_p5", "lowres_p3_nonsq"])
+def test_decode_lowres_pipeline_switches_match_reference(golden_dir, name):
+    g = _load(golden_dir, "decode_branches.npz")
+    P, H, W, oh, ow, seed = [int(v) for v in g[name + "_meta"]]
+    refined, tags = synth.make_lowres_maps(P, H, W, seed=seed)
+    hms = decode_ref.upsample_bilinear(torch.from_numpy(refined), oh, ow)
+    aes = decode_ref.upsample_bilinear(torch.from_numpy(tags), oh, ow)
+    hp = decode_ref.HeatmapParserRef()
+    for a, r in SWITCHES[1:]:
+        ans, scores = hp.parse(hms.clone(), aes.unsqueeze(-1).clone(), adjust=a, refine=r)
+        _check_branch(g, "%s_a%d_r%d" % (name, a, r), ans, scores)

@@ -22,6 +22,8 @@ What gets pinned:
   munkres_vectors.npz Munkres().compute() of the REAL PyPI package on tie-heavy cost matrices
   match_vectors.npz   match_by_tag (group.py:26-97) on that package, tie-heavy candidate tables
   student_steps.npz   AttentionStudentSteps (students.py:786-1063) outputs + its state-dict contract
+  decode_branches.npz tag_per_joint=False (the AGS branch of legacy/valid_ae1dim.py), adjust / refine switched off
+  ref_selfspread.npz  the reference against itself (oneDNN off / 1 thread): the spread the GPU tests bound HIP by
 
 ``rtpe/third_party/group.py`` imports the PyPI package ``munkres`` (unpinned, not vendored).  It
 is not installed for this interpreter, but the pure-Python module of munkres 1.1.4 sits in the
@@ -221,6 +223,114 @@ def gen_e2e(ref):
         out.update(_pack(variant + "_", *res, stride=8))
         print("e2e 640", variant, "people", len(res[3]), "candidates > 0.1:", int((res[2]["val_k"] > 0.1).sum()))
     np.savez_compressed(os.path.join(OUT, "e2e_640.npz"), **out)
+
+
+def gen_selfspread(ref):
+    """How far the reference is from ITSELF: the half wrapper (helpers.py:69-71) run a second time with PyTorch-CPU's
+    other convolution kernels (torch.backends.mkldnn off) and with one thread instead of eight, same weights, same
+    input.  fp16 storage after every conv / BN / add makes the result depend on the fp32 accumulation order inside the
+    convolutions, which differs between those kernels: this spread is a property of the reference's arithmetic and is
+    what the GPU parity tests bound the HIP path by.  Cases = the whole-net fixtures above (same sampling strides):
+    W0 / W2 at 128x192, images 0 / 17 / 31 of the 640x640 batch-32 set, and the two bundled COCO images.
+    Stored per case: the second run's sampled outputs (fp16) and full-tensor statistics of |run2 - run1| per map
+    group (heat maps preds[:, :17], tags preds[:, 17:], refined): max, mean, fraction within 1e-3.
+    ~200 s per 640x640 image with oneDNN off: the file is rewritten after every case."""
+    from PIL import Image
+    from oracle import preprocess_ref
+    path = os.path.join(OUT, "ref_selfspread.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+
+    def stats(a, b):
+        d = (a.double() - b.double()).abs()
+        return [float(d.max()), float(d.mean()), float((d <= 1e-3).double().mean())]
+
+    def groups(p0, r0, p1, r1):
+        return np.array([stats(p0[:, :17], p1[:, :17]), stats(p0[:, 17:], p1[:, 17:]), stats(r0, r1)], np.float64)
+
+    def case(name, model, x, stride):
+        if name + "_stats_mkldnn_off" in out:
+            return
+        import time
+        t0 = time.time()
+        with torch.no_grad():
+            p0, r0 = model(x)                                   # as every other fixture: oneDNN on, 8 threads
+            torch.set_num_threads(1)
+            p1, r1 = model(x)
+            torch.set_num_threads(8)
+            with torch.backends.mkldnn.flags(enabled=False):
+                p2, r2 = model(x)
+        out[name + "_stats_threads1"] = groups(p0, r0, p1, r1)
+        out[name + "_stats_mkldnn_off"] = groups(p0, r0, p2, r2)
+        if stride:
+            out[name + "_alt_preds_s%d" % stride], out[name + "_alt_refined_s%d" % stride] = _sample(p2, stride), _sample(r2, stride)
+        else:
+            out[name + "_alt_preds"], out[name + "_alt_refined"] = p2.numpy().astype(np.float16), r2.numpy().astype(np.float16)
+        np.savez_compressed(path, **out)
+        print("%-22s %5.0f s  oneDNN off vs on: heat %.2e / %.4f%%  tags %.2e / %.2f%%  refined %.2e / %.4f%%" % (
+            name, time.time() - t0, out[name + "_stats_mkldnn_off"][0, 0], 100 * out[name + "_stats_mkldnn_off"][0, 2],
+            out[name + "_stats_mkldnn_off"][1, 0], 100 * out[name + "_stats_mkldnn_off"][1, 2],
+            out[name + "_stats_mkldnn_off"][2, 0], 100 * out[name + "_stats_mkldnn_off"][2, 2]), flush=True)
+
+    imgs = {}
+    for name in ("000000001000", "000000002685"):
+        img = np.array(Image.open(os.path.join(REF, "data", name + ".jpg")).convert("RGB"))
+        t, _, _ = preprocess_ref.warp_normalize(img, 640, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+        imgs[name] = torch.from_numpy(t)[None]
+    xs = synth.make_images(1, 128, 192)
+    xb = synth.make_images(32, 640, 640)
+    for variant in ("W0", "W2"):
+        model = ref.teacher(ref.weights(variant))
+        case(variant + "_small", model, xs, 0)
+        for i in ((0, 17, 31) if variant == "W0" else (0, 31)):
+            case("%s_img%d" % (variant, i), model, xb[i:i + 1], 4 if i == 0 else 8)
+        for name, t in imgs.items():
+            case("%s_%s" % (variant, name), model, t, 8)
+
+
+def gen_decode_branches(ref):
+    """The public branches of HeatmapParser.parse the other fixtures never take (group.py:266-287):
+    ``tag_per_joint=False`` with ONE tag map for all joints, tag tensor (1,1,h,w,1) - what the reference's
+    upstream-faithful script runs (legacy/valid_ae1dim.py:177,191-199, the ``AGS`` branch) - and ``adjust=False`` /
+    ``refine=False`` in every combination, on two blob sets each; plus the low-res -> bilinear -> parse pipeline of
+    validate_hhrnet.py:93-101 with the same switches (the fused ``parse_lowres`` entry of this repo)."""
+    out = {}
+
+    def run(name, det_t, tag_t, per_joint, adjust, refine):
+        kw = dict(HP_KW)
+        kw["tag_per_joint"] = per_joint
+        parser = ref.Parser(num_joints=NUM_HEATMAPS, **kw)
+        ans, scores = parser.parse(det_t.clone(), tag_t.clone(), adjust=adjust, refine=refine)
+        key = "%s_a%d_r%d" % (name, int(adjust), int(refine))
+        out[key + "_n"] = np.array([len(a) if getattr(a, "ndim", 0) == 3 else 0 for a in ans], np.int32)
+        out[key + "_final"] = np.asarray(ans[0], np.float32)
+        out[key + "_scores"] = np.array(scores, np.float32)
+        return len(ans[0])
+
+    for name, P, h, w, seed in (("ags_p4", 4, 480, 640, 11), ("ags_p12", 12, 640, 640, 12)):
+        det, tag = synth.make_decode_maps(P, h, w, seed=seed)
+        ags = np.ascontiguousarray(tag.max(axis=1, keepdims=True))            # (1,1,h,w,1): one map for all joints
+        out[name + "_meta"] = np.array([P, h, w, seed])
+        det_t, ags_t = torch.from_numpy(det), torch.from_numpy(ags)
+        kw = dict(HP_KW)
+        kw["tag_per_joint"] = False
+        tk = ref.Parser(num_joints=NUM_HEATMAPS, **kw).top_k(det_t, ags_t)
+        out[name + "_val_k"], out[name + "_loc_k"], out[name + "_tag_k"] = tk["val_k"], tk["loc_k"].astype(np.int32), tk["tag_k"]
+        n = [run(name, det_t, ags_t, False, a, r) for a, r in ((True, True), (False, True), (True, False), (False, False))]
+        print(name, "people", n)
+    for name, P, h, w, seed, D in (("sw_p6", 6, 480, 640, 13, 1), ("sw_p9_d2", 9, 320, 384, 14, 2)):
+        det, tag = synth.make_decode_maps(P, h, w, seed=seed, tag_dim=D)
+        out[name + "_meta"] = np.array([P, h, w, seed, D])
+        n = [run(name, torch.from_numpy(det), torch.from_numpy(tag), True, a, r)
+             for a, r in ((False, True), (True, False), (False, False))]
+        print(name, "people", n)
+    for name, P, H, W, oh, ow, seed in (("lowres_p5", 5, 640, 640, 640, 640, 15), ("lowres_p3_nonsq", 3, 640, 768, 555, 640, 16)):
+        refined, tags = synth.make_lowres_maps(P, H, W, seed=seed)
+        hms = torch.nn.functional.interpolate(torch.from_numpy(refined), (oh, ow), mode="bilinear", align_corners=True)
+        aes = torch.nn.functional.interpolate(torch.from_numpy(tags), (oh, ow), mode="bilinear", align_corners=True)
+        out[name + "_meta"] = np.array([P, H, W, oh, ow, seed])
+        n = [run(name, hms, aes.unsqueeze(-1), True, a, r) for a, r in ((False, True), (True, False), (False, False))]
+        print(name, "people", n)
+    np.savez_compressed(os.path.join(OUT, "decode_branches.npz"), **out)
 
 
 def gen_munkres(real):
@@ -464,7 +574,7 @@ def main():
         gen_base()
     ref = Ref()
     for name, fn in (("w0_640", gen_w0_640), ("w2", gen_w2), ("two_images", gen_two_images), ("e2e", gen_e2e),
-                     ("student_steps", gen_student_steps)):
+                     ("student_steps", gen_student_steps), ("selfspread", gen_selfspread), ("decode_branches", gen_decode_branches)):
         if name in only:
             fn(ref)
     if "munkres" in only:
