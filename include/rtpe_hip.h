@@ -208,7 +208,10 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
  * variants for A/B measurements in one process).  "block_pc" = 0: the fused BasicBlock never runs on the
  * producer / consumer kernel (default 1: wherever H % 8 == 0 and W % 16 == 0; env RTPE_BLOCK_PC).  "block_ring" = 1:
  * the fused BasicBlock kernel streams its weights through a 3-slot LDS ring instead of keeping them resident
- * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc"). */
+ * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc").  "stream_v2" (env RTPE_STREAM_V2): the second-
+ * generation streaming conv kernel (an experiment that did not beat the first one: csrc/conv_stream.hip) is 0 = never used
+ * (default), 1 = one more family of launch shapes for the autotuner,
+ * 2 = the only streaming kernel (also for un-tuned launches: the layer-level tests run it this way). */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */

@@ -63,8 +63,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "", ""};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", ""};
 static const int kOptionDefault[kNumOptions] = {0, 1, 0, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
@@ -316,7 +316,7 @@ static std::vector<char> plane_tensors(const rtpe_hrnet* h, int N, int H, int W,
     const rtpe_tensor_desc& ti = h->tensors[d.in_t];
     const ConvTile t = (tuned && (*tuned)[i * 4].nt) ? (*tuned)[i * 4]
                                                       : conv_make_tile(o.plan[0], N, H >> ti.ds_log2, W >> ti.ds_log2);
-    if (t.kind != 2) {
+    if (t.kind != 2 && t.kind != 3) {
       plane[d.in_t] = plane[d.out_t] = 0;
       if (d.res_t >= 0) plane[d.res_t] = 0;
     }
@@ -463,7 +463,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         if (force) tile0 = *force;
         else if (tuned && (*tuned)[i * 4].nt) tile0 = (*tuned)[i * 4];
         else tile0 = conv_make_tile(o.plan[0], N, Hi, Wi);
-        merge = tile0.kind != 2;
+        merge = tile0.kind == 0;
         for (int k = 1; k < o.n_geom && merge; ++k) {
           const ConvPlan &p0 = o.plan[0], &pk = o.plan[k];
           merge = pk.mt == p0.mt && pk.cc == p0.cc && pk.kc == p0.kc && pk.n_cchunks == p0.n_cchunks &&
@@ -738,6 +738,15 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
             hd[2] / hd[5], hd[3] / hd[5], hd[12] / units, hd[13] / units, hd[4] / units, hd[14] / units, hd[10] / units, hd[6] / hd[11],
             hd[7] / hd[11], hd[8] / hd[11], hd[9] / hd[11]);
   }
+  else if (tile.kind == 3 && hd[4]) {
+    const unsigned long long nw = (unsigned long long)tile.grid * 4, stages = hd[4], units = hd[14] ? hd[14] : 1;
+    const unsigned long long nl = (unsigned long long)tile.grid * (tile.n_wslots == 3 ? 3 : 4), lstages = stages / 4 * (tile.n_wslots == 3 ? 3 : 4);
+    fprintf(stderr, "stream2 conv %dx%d nt%d grid %d wslots %d | per MFMA wave: total %llu cycles, %llu units | per stage: waitM %llu half0 %llu waitH %llu half1 %llu | "
+            "per unit: waitE %llu bn->slab %llu waitS %llu | tile loaders per stage: waitM %llu drain(+H) %llu rendezvous %llu wait-tile %llu write %llu load-issue %llu\n",
+            tile.th, tile.tw, tile.nt, tile.grid, tile.n_wslots, hd[15] / nw, units / nw, hd[0] / stages, hd[1] / stages, hd[2] / stages, hd[3] / stages,
+            hd[5] / units, hd[6] / units, hd[7] / units, hd[8] / lstages, hd[9] / lstages, hd[10] / lstages, hd[11] / lstages, hd[12] / lstages, hd[13] / lstages);
+    (void)nl;
+  }
   else if (hd[5])
     fprintf(stderr, "conv stamps (kind %d): n %llu | per wave(-unit) cycles: setup %llu stage/wait1 %llu kloop %llu epilogue %llu total/wait2 %llu\n",
             tile.kind, hd[5], hd[0] / hd[5], hd[1] / hd[5], hd[2] / hd[5], hd[3] / hd[5], hd[4] / hd[5]);
@@ -802,7 +811,7 @@ extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_
   ConvPlan plans[4];
   for (int k = 0; k < 4; ++k) plans[k] = conv_make_plan(ConvGeom{cin, cout, 4, 2, k, 2, 1});
   const ConvTile tile0 = conv_make_tile(plans[0], N, H, W);
-  bool merge = merge_deconv && tile0.kind != 2;
+  bool merge = merge_deconv && tile0.kind == 0;
   for (int k = 1; k < 4 && merge; ++k)
     merge = plans[k].mt == plans[0].mt && plans[k].cc == plans[0].cc && plans[k].kc == plans[0].kc &&
             plans[k].n_cchunks == plans[0].n_cchunks && plans[k].n_cb == plans[0].n_cb &&
@@ -902,7 +911,8 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     return RTPE_OK;
   }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : (int32_t)t.lds_bytes;
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
+                                                            : (int32_t)t.lds_bytes;   // v2: "/8" weight ring, "/9" resident weights
   return RTPE_OK;
 }
 

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kNumOptions = 4 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kNumOptions = 4 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -153,7 +153,7 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int th, tw;
   size_t lds_bytes;
   int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
-                        // (conv_stream.hip)
+                        // (conv_stream.hip), 3: streaming v2 (tiles through loader registers, loaders store)
   int grid;             // streaming: number of workgroups
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
@@ -182,6 +182,12 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
 bool conv_stream_supports(const ConvPlan& p);
 size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots);
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+// second-generation streaming kernel (ConvTile::kind == 3): tiles through the loader waves' registers, the loaders
+// also run the residual / ReLU / store phase; 4 MFMA + 4 loader waves, two halo buffers
+size_t conv_stream2_lds(const ConvPlan& p, int buf_bytes, int n_wslots);
+bool conv_stream2_tile_fits(int halo_h, int halo_w, bool resident);
+bool conv_stream2_drain_fits(int mt, int nt, int halo_h, int halo_w, bool resident);
+int conv_stream2_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,

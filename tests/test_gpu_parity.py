@@ -120,6 +120,45 @@ def test_conv_layer(nat, case):
     assert same > 0.97, "only %.4f identical" % same
 
 
+STREAM2_CASES = [
+    # cin, cout, stride, H, W, N, residual: shapes the second-generation streaming kernel offers launch shapes for
+    # (resident weights or stride 2), several units per workgroup, partial tiles, no residual / no ReLU paths
+    (96, 96, 1, 80, 80, 8, True), (96, 96, 1, 37, 51, 3, True), (96, 96, 1, 40, 32, 3, False), (48, 48, 1, 64, 80, 4, True),
+    (48, 96, 2, 80, 80, 4, False), (48, 192, 2, 48, 80, 3, False),
+]
+
+
+@pytest.mark.parametrize("case", STREAM2_CASES, ids=lambda c: "stream2_%d-%d_s%d_%dx%d_n%d" % c[:6])
+def test_second_generation_streaming_kernel_is_bit_identical(nat, case):
+    """csrc/conv_stream.hip, conv_stream2_kernel (opt-in: option "stream_v2"): tiles staged through the loader waves'
+    registers, the loaders run the residual / ReLU / store phase.  An experiment that did not beat the first kernel
+     and is never selected by default; where it offers launch shapes it must give the same bits."""
+    cin, cout, s, H, W, N, use_res = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(N, H, W, cin, generator=g).half().to("cuda:0")
+    w = ((torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5).half().contiguous().numpy()
+    a = (torch.rand(cout, generator=g) * 0.4 + 0.8).numpy()
+    b = (torch.randn(cout, generator=g) * 0.1).numpy()
+    Ho, Wo = H // s, W // s
+    res = torch.randn(N, Ho, Wo, cout, generator=g).half().to("cuda:0") if use_res else None
+    fp = ctypes.POINTER(ctypes.c_float)
+    L = nat.lib()
+    outs = []
+    try:
+        for v2 in (0, 2):
+            nat.check(L.rtpe_set_option(b"stream_v2", v2))
+            y = torch.full((N, Ho, Wo, cout), float("nan"), dtype=torch.float16, device="cuda:0")
+            flags = (nat.F_RELU if use_res else 0) | nat.F_ROUND_CONV
+            nat.check(L.rtpe_conv2d_nhwc(x.data_ptr(), N, H, W, cin, w.ctypes.data, a.ctypes.data_as(fp), b.ctypes.data_as(fp),
+                                         cout, 3, s, flags, res.data_ptr() if use_res else None, y.data_ptr(),
+                                         nat.stream_ptr(torch.device("cuda:0"))))
+            outs.append(y.cpu())
+    finally:
+        nat.check(L.rtpe_set_option(b"stream_v2", 0))
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 @pytest.mark.parametrize("hw,n,f32in", [((64, 96), 2, True), ((160, 224), 3, True), ((32, 32), 1, False), ((96, 352), 2, True)])
 def test_stem_and_nchw_head_epilogues(nat, hw, n, f32in):
     """layer-level check of the two kernels that touch the NCHW boundary, through the ABI (rtpe_hrnet_create /
