@@ -20,6 +20,18 @@ import re
 import sys
 
 
+def csrc_sha16():
+    """the same hash bench.py computes over csrc/ and the header"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "realtime-pose-estimation_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)) + ["../../include/rtpe_hip.h"]:
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def short(name):
     m = re.match(r"_ZN4rtpe(\d+)([A-Za-z_0-9]+)", name)
     if m:
@@ -133,6 +145,7 @@ def main():
     cfg = bench.get("config", {})
     out = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 "
                       "(one pass per group: fetch, write, mfma, lds; tools/pmc_passes.sh)",
+           "csrc_sha16": csrc_sha16(),        # the kernel sources these counters belong to (bench.py compares)
            "batch": cfg.get("batch_per_gpu"), "size": 640, "unprofiled_bench": {k: bench.get(k) for k in ("value", "ms_per_step")},
            "notes": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); values are means per "
                     "launch over the 6 timed forwards; kernels are serialised under --pmc, so the times are not the bench's",
