@@ -211,7 +211,9 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
  * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc").  "stream_v2" (env RTPE_STREAM_V2): the second-
  * generation streaming conv kernel (an experiment that did not beat the first one: csrc/conv_stream.hip) is 0 = never used
  * (default), 1 = one more family of launch shapes for the autotuner,
- * 2 = the only streaming kernel (also for un-tuned launches: the layer-level tests run it this way). */
+ * 2 = the only streaming kernel (also for un-tuned launches: the layer-level tests run it this way).  "direct_1x1" (env
+ * RTPE_DIRECT_1X1): the 1x1 conv kernel without a staged input tile (csrc/conv_direct.hip) is 0 = never used, 1 = one more launch
+ * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved). */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */

@@ -607,7 +607,20 @@ static ConvTile make_stream2_tile(const ConvPlan& p, int N, int H_pos, int W_pos
   return best;
 }
 
+static bool direct_tile(const ConvPlan& p, ConvTile* out) {
+  const int mb = conv_direct_mb(p);
+  if (mb == 0 || get_option(kOptDirect1x1) == 0) return false;
+  memset(out, 0, sizeof(*out));
+  out->kind = 4; out->nt = 1; out->waves = 4; out->th = 8; out->tw = 8;   // (th x tw = 16 nt waves: the common check)
+  out->grid = mb;
+  return true;
+}
+
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+  {
+    ConvTile t;
+    if (direct_tile(p, &t)) return t;
+  }
   if (get_option(kOptStreamV2) == 2 && conv_stream_supports(p)) {
     ConvTile t = make_stream2_tile(p, N, H_pos, W_pos);
     if (t.nt) return t;
@@ -734,7 +747,11 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
         out->push_back(st);
     }
   }
-  // streaming v2 (RTPE_CONV_STREAM bit 1; default on): its own tile list
+  {
+    ConvTile dt;
+    if (direct_tile(p, &dt)) out->push_back(dt);                 // 1x1: no staged tile at all (conv_direct.hip)
+  }
+  // streaming v2 (option "stream_v2", default off): its own tile list
   if (get_option(kOptStreamV2) != 0) {
     for (const Tile2Cand& c : kCands2) {
       const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
@@ -765,6 +782,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 2) return conv_stream_launch(p, t, a, s);
   if (t.kind == 3) return conv_stream2_launch(p, t, a, s);
+  if (t.kind == 4) return conv_direct_launch(p, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
                "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");
 #define RTPE_V(MTv, NTv, Wv)                                                                  \

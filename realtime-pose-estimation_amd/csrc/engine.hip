@@ -63,9 +63,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", ""};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 0};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -911,7 +911,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     return RTPE_OK;
   }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
                                                             : (int32_t)t.lds_bytes;   // v2: "/8" weight ring, "/9" resident weights
   return RTPE_OK;
 }

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kNumOptions = 4 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kNumOptions = 4 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -153,7 +153,7 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int th, tw;
   size_t lds_bytes;
   int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
-                        // (conv_stream.hip), 3: streaming v2 (tiles through loader registers, loaders store)
+                        // (conv_stream.hip), 3: streaming v2 (tiles through loader registers, loaders store), 4: direct 1x1 (conv_direct.hip)
   int grid;             // streaming: number of workgroups
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
@@ -188,6 +188,10 @@ size_t conv_stream2_lds(const ConvPlan& p, int buf_bytes, int n_wslots);
 bool conv_stream2_tile_fits(int halo_h, int halo_w, bool resident);
 bool conv_stream2_drain_fits(int mt, int nt, int halo_h, int halo_w, bool resident);
 int conv_stream2_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+// 1x1 convs without a staged tile (conv_direct.hip, ConvTile::kind == 4): B fragments straight from global memory,
+// weights in registers; conv_direct_mb = cout tiles per wave, 0 when the layer is not one the kernel takes
+int conv_direct_mb(const ConvPlan& p);
+int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,

@@ -120,6 +120,45 @@ def test_conv_layer(nat, case):
     assert same > 0.97, "only %.4f identical" % same
 
 
+DIRECT_CASES = [
+    # cin, cout, H, W, N, residual, relu: every 1x1 layer class of the w48 network the direct kernel takes, at sizes
+    # with many tiles per wave, a ragged last tile (pixel count not a multiple of 16) and tensors smaller than one tile
+    (64, 256, 40, 56, 4, True, True), (256, 64, 40, 56, 4, False, True), (64, 256, 23, 37, 3, False, False),
+    (64, 64, 32, 48, 2, False, True), (96, 48, 20, 28, 3, False, False), (192, 48, 10, 14, 3, False, False),
+    (192, 96, 10, 14, 3, False, False), (384, 48, 5, 7, 3, False, False), (384, 96, 5, 7, 3, False, False),
+    (384, 192, 5, 7, 2, False, False), (96, 48, 5, 3, 1, False, False), (256, 64, 3, 5, 1, False, True),
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "direct_%d-%d_%dx%d_n%d" % c[:5])
+def test_direct_1x1_kernel_is_bit_identical(nat, case):
+    """csrc/conv_direct.hip (1x1 convs without a staged input tile: B fragments straight from global memory, weights in
+    registers; the default for these layers) against the one-workgroup-per-tile kernel (option "direct_1x1" = 0): same
+    k order and rounding points, hence the same bits - the autotuner may pick either"""
+    cin, cout, H, W, N, use_res, relu = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(N, H, W, cin, generator=g).half().to("cuda:0")
+    w = ((torch.rand(cout, cin, 1, 1, generator=g) * 2 - 1) / cin ** 0.5).half().contiguous().numpy()
+    a = (torch.rand(cout, generator=g) * 0.4 + 0.8).numpy()
+    b = (torch.randn(cout, generator=g) * 0.1).numpy()
+    res = torch.randn(N, H, W, cout, generator=g).half().to("cuda:0") if use_res else None
+    fp = ctypes.POINTER(ctypes.c_float)
+    L = nat.lib()
+    outs = []
+    try:
+        for opt in (0, 1):
+            nat.check(L.rtpe_set_option(b"direct_1x1", opt))
+            y = torch.full((N, H, W, cout), float("nan"), dtype=torch.float16, device="cuda:0")
+            nat.check(L.rtpe_conv2d_nhwc(x.data_ptr(), N, H, W, cin, w.ctypes.data, a.ctypes.data_as(fp), b.ctypes.data_as(fp),
+                                         cout, 1, 1, (nat.F_RELU if relu else 0) | nat.F_ROUND_CONV,
+                                         res.data_ptr() if use_res else None, y.data_ptr(), nat.stream_ptr(torch.device("cuda:0"))))
+            outs.append(y.cpu())
+    finally:
+        nat.check(L.rtpe_set_option(b"direct_1x1", 1))
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 STREAM2_CASES = [
     # cin, cout, stride, H, W, N, residual: shapes the second-generation streaming kernel offers launch shapes for
     # (resident weights or stride 2), several units per workgroup, partial tiles, no residual / no ReLU paths
