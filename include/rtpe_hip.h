@@ -138,6 +138,11 @@ typedef struct rtpe_op_desc {
                               [2] channels written to the NHWC output (0: all
                               that fit; used to lay the HDC branches of a
                               ContextAwareModule side by side)                */
+  int32_t lane;            /* 0..3: the branches of a HighResolutionModule are independent
+                              (pose_higher_hrnet.py:242-243 runs them one after another); ops of
+                              different lanes inside one region may run concurrently on internal
+                              streams that fork from / join into the caller's stream               */
+  int32_t region;          /* 0: outside any parallel region; ops of one region are contiguous      */
 } rtpe_op_desc;
 
 typedef struct rtpe_hrnet rtpe_hrnet;
@@ -213,7 +218,10 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
  * (default), 1 = one more family of launch shapes for the autotuner,
  * 2 = the only streaming kernel (also for un-tuned launches: the layer-level tests run it this way).  "direct_1x1" (env
  * RTPE_DIRECT_1X1): the 1x1 conv kernel without a staged input tile (csrc/conv_direct.hip) is 0 = never used, 1 = one more launch
- * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved). */
+ * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved).  "lanes" (env RTPE_LANES): the
+ * independent branches of a parallel region run 0 = one after another on the caller's stream, 1 = concurrently on internal
+ * streams, 2 = concurrently when the batch is small (N * H * W <= 4 * 640 * 640: the kernels of one branch cannot fill the chip;
+ * default). */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */

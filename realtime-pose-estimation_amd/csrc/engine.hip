@@ -57,15 +57,23 @@ struct rtpe_hrnet {
   char* arena;        // device: packed weights + affine params
   size_t arena_bytes;
   int n_preds, n_refined;
+  // parallel regions (rtpe_op_desc::lane / region): internal streams for lanes 1..3 and one event per op whose output
+  // another lane reads, created on first use; wait_ops[i] = ops of other lanes whose output op i reads
+  hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> op_event;
+  std::vector<char> needs_event;
+  std::vector<std::vector<int>> wait_ops;
+  hipEvent_t fork_event = nullptr;
+  bool has_regions = false;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1", "lanes", "", "", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1", "RTPE_LANES", "", "", ""};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 2, 0, 0, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -212,6 +220,33 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
   }
   h->arena_bytes = off;
   {
+    // cross-lane dependencies inside parallel regions: the last writer of every tensor an op reads, when it ran on
+    // another lane of the same region (a region starts with a fork from and ends with a join into the caller's stream,
+    // so nothing outside it needs an event)
+    h->needs_event.assign(n_ops, 0);
+    h->wait_ops.assign(n_ops, std::vector<int>());
+    std::vector<int> writer(h->tensors.size(), -1);
+    for (int i = 0; i < n_ops; ++i) {
+      const rtpe_op_desc& d = h->ops[i].d;
+      if (d.lane < 0 || d.lane > 3 || d.region < 0) { set_error("op %d: lane %d region %d", i, d.lane, d.region); delete h; return RTPE_E_INVALID; }
+      if (d.region > 0) h->has_regions = true;
+      if (d.region == 0 && d.lane != 0) { set_error("op %d: a lane outside a region", i); delete h; return RTPE_E_INVALID; }
+      std::vector<int> reads;
+      if (d.kind != RTPE_OP_FUSE && d.in_t >= 0) reads.push_back(d.in_t);
+      if (d.res_t >= 0) reads.push_back(d.res_t);
+      for (int t = 0; t < d.n_terms; ++t) reads.push_back(d.term_t[t]);
+      if (d.out_t >= 0) reads.push_back(d.out_t);          // (a second writer of a shared buffer: ordered behind the first)
+      for (int t : reads) {
+        const int j = writer[t];
+        if (j >= 0 && h->ops[j].d.region == d.region && d.region > 0 && h->ops[j].d.lane != d.lane) {
+          h->needs_event[j] = 1;
+          h->wait_ops[i].push_back(j);
+        }
+      }
+      if (d.out_t >= 0) writer[d.out_t] = i;
+    }
+  }
+  {
     static const int plane_major = getenv("RTPE_PLANE_MAJOR") ? atoi(getenv("RTPE_PLANE_MAJOR")) : 1;
     h->plane_ok.assign(h->tensors.size(), 0);
     for (size_t t = 0; plane_major && t < h->tensors.size(); ++t) {
@@ -278,6 +313,9 @@ extern "C" int rtpe_hrnet_destroy(rtpe_hrnet* h) {
   DeviceGuard guard(h->device);
   for (auto& kv : h->records)
     for (auto& e : kv.second) hipEventDestroy(e);
+  for (auto& e : h->op_event) if (e) hipEventDestroy(e);
+  if (h->fork_event) hipEventDestroy(h->fork_event);
+  for (int l = 1; l < 4; ++l) if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]);
   if (h->arena) hipFree(h->arena);
   delete h;
   return RTPE_OK;
@@ -367,7 +405,7 @@ static int read_op_times(const rtpe_hrnet* h, const Events& ev, bool fused_mode,
 }
 
 static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
-               int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, float* op_ms, int n_ms,
+               int out_dtype, void* ws, size_t ws_bytes, hipStream_t s_main, float* op_ms, int n_ms,
                int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
                std::vector<hipEvent_t>* rec = nullptr, const void* aux = nullptr) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
@@ -394,7 +432,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     RTPE_REQUIRE(n_ms >= (int)h->ops.size(), "forward_timed: op_ms too small");
     ev.resize(h->ops.size() + 1);
     for (auto& e : ev) RTPE_HIP_CHECK(hipEventCreate(&e));
-    RTPE_HIP_CHECK(hipEventRecord(ev[0], s));
+    RTPE_HIP_CHECK(hipEventRecord(ev[0], s_main));
   }
   if (rec) {                         // non-blocking recording into caller-kept events
     if (rec->size() != h->ops.size() + 1) {
@@ -402,7 +440,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       rec->resize(h->ops.size() + 1);
       for (auto& e : *rec) RTPE_HIP_CHECK(hipEventCreate(&e));
     }
-    RTPE_HIP_CHECK(hipEventRecord((*rec)[0], s));
+    RTPE_HIP_CHECK(hipEventRecord((*rec)[0], s_main));
   }
   const std::vector<ConvTile>* tuned = nullptr;
   {
@@ -411,11 +449,58 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
   }
   std::vector<char> plane(h->tensors.size(), 0);
   if (only_op < 0 && force == nullptr) plane = plane_tensors(h, N, H, W, tuned);
+  // Parallel regions (the branches of a HighResolutionModule, pose_higher_hrnet.py:242-243, and the conversion convs of
+  // its fuse layers are independent): with lanes on, the ops of lane k > 0 go to an internal stream that forks from the
+  // caller's stream at the region's first op and joins it behind its last; an op waits for the events of the ops of
+  // other lanes whose output it reads.  Timed / recorded / single-op runs stay on one stream (one op after another).
+  bool lanes_on = false;
+  if (h->has_regions && !timed && rec == nullptr && only_op < 0 && force == nullptr) {
+    const int opt = get_option(kOptLanes);
+    lanes_on = opt == 1 || (opt == 2 && (long long)N * H * W <= 4ll * 640 * 640);
+  }
+  if (lanes_on && h->fork_event == nullptr) {
+    for (int l = 1; l < 4; ++l) RTPE_HIP_CHECK(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    h->op_event.assign(h->ops.size() + 4, nullptr);
+    for (size_t i = 0; i < h->ops.size(); ++i)
+      if (h->needs_event[i]) RTPE_HIP_CHECK(hipEventCreateWithFlags(&h->op_event[i], hipEventDisableTiming));
+    for (size_t l = 0; l < 4; ++l) RTPE_HIP_CHECK(hipEventCreateWithFlags(&h->op_event[h->ops.size() + l], hipEventDisableTiming));
+    RTPE_HIP_CHECK(hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming));
+  }
+  int cur_region = 0;
+  bool lane_used[4] = {false, false, false, false};
+  auto join_lanes = [&]() -> hipError_t {
+    for (int l = 1; l < 4; ++l) {
+      if (!lane_used[l]) continue;
+      hipEvent_t e = h->op_event[h->ops.size() + l];
+      hipError_t er = hipEventRecord(e, h->lane_stream[l]);
+      if (er == hipSuccess) er = hipStreamWaitEvent(s_main, e, 0);
+      if (er != hipSuccess) return er;
+      lane_used[l] = false;
+    }
+    return hipSuccess;
+  };
   for (size_t i = 0; i < h->ops.size(); ++i) {
     if (only_op >= 0 && (int)i != only_op) continue;
     const OpState& o = h->ops[i];
     const rtpe_op_desc& d = o.d;
     int rc = RTPE_OK;
+    hipStream_t s = s_main;
+    if (lanes_on) {
+      if (d.region != cur_region) {
+        if (cur_region > 0) RTPE_HIP_CHECK(join_lanes());
+        cur_region = d.region;
+        if (cur_region > 0) {                            // fork: every lane starts behind what the caller's stream holds
+          RTPE_HIP_CHECK(hipEventRecord(h->fork_event, s_main));
+          for (int l = 1; l < 4; ++l) RTPE_HIP_CHECK(hipStreamWaitEvent(h->lane_stream[l], h->fork_event, 0));
+        }
+      }
+      if (cur_region > 0) {
+        if (d.lane > 0) { s = h->lane_stream[d.lane]; lane_used[d.lane] = true; }
+        for (int j : h->wait_ops[i]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
+        if (o.fuse == 1 && i + 1 < h->ops.size())        // the block's second conv is launched with this one
+          for (int j : h->wait_ops[i + 1]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
+      }
+    }
     if (d.kind == RTPE_OP_STEM) {
       const rtpe_tensor_desc& to = h->tensors[d.out_t];
       StemArgs a;
@@ -605,10 +690,12 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       rc = fuse_launch(a, s);
     }
     if (rc != RTPE_OK) return rc;
+    if (lanes_on && cur_region > 0 && h->needs_event[i]) RTPE_HIP_CHECK(hipEventRecord(h->op_event[i], s));
     const bool has_event = op_has_event(h, i, force == nullptr && only_op < 0);
     if (timed && has_event) RTPE_HIP_CHECK(hipEventRecord(ev[i + 1], s));
     if (rec && has_event) RTPE_HIP_CHECK(hipEventRecord((*rec)[i + 1], s));
   }
+  if (lanes_on && cur_region > 0) RTPE_HIP_CHECK(join_lanes());
   if (timed) {
     RTPE_HIP_CHECK(hipEventSynchronize(ev.back()));
     const int rc2 = read_op_times(h, ev, force == nullptr && only_op < 0, op_ms);

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kNumOptions = 4 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kOptLanes = 4, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's

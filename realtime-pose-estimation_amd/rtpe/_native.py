@@ -32,7 +32,7 @@ class OpDesc(Structure):
                 ("ksize", c_int32), ("stride", c_int32),
                 ("w_off", c_int64), ("ab_off", c_int64),
                 ("n_terms", c_int32), ("term_t", c_int32 * 4), ("term_up", c_int32 * 4),
-                ("reserved", c_int32 * 3)]
+                ("reserved", c_int32 * 3), ("lane", c_int32), ("region", c_int32)]
 
 
 _SIGS = {

@@ -1580,8 +1580,9 @@ def test_plane_major_inner_tensors_do_not_change_the_network_output(nat, teacher
 
 def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat, teacher, tmp_path):
     """two implementations of the same arithmetic: the product configuration (streaming kernel, fused 48-channel
-    blocks, plane-major inner tensors) and a second process that runs every conv on the one-workgroup-per-tile
-    kernel with NHWC tensors must give the SAME bits on a large non-square batch (416x960: partial tiles on both
+    blocks, plane-major inner tensors, direct 1x1 kernel, parallel lanes at this small batch) and a second process
+    that runs every conv on the one-workgroup-per-tile kernel with NHWC tensors, one op after another, must give the
+    SAME bits on a large non-square batch (416x960: partial tiles on both
     axes, many units per persistent workgroup)"""
     import subprocess
     import sys
@@ -1607,10 +1608,38 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
         "np.savez(%r, p=p.cpu().numpy(), r=r.cpu().numpy())\n"
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
-    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0")
+    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
+
+
+def test_parallel_lanes_do_not_change_the_network_output(nat, teacher, w48_shapes):
+    """the branches of a HighResolutionModule (and the conversion convs of its fuse layers) run on internal streams that
+    fork from / join into the caller's stream (option "lanes": default at small batches): the outputs must be the bits of
+    the one-op-after-another run - half wrapper and fp32, odd sizes, repeated (a missing dependency would be a race:
+    each configuration runs four times and every run must agree), also with the workspace of another shape in between"""
+    from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+    L = nat.lib()
+    m16, sd = teacher("W1")
+    m32 = PoseHigherResolutionNet()
+    m32.load_state_dict(sd, strict=True)
+    m32 = m32.to("cuda:0").eval()
+    try:
+        for model, n, hw in ((m16, 1, (640, 640)), (m16, 3, (160, 224)), (m16, 6, (96, 128)), (m32, 1, (256, 320)), (m32, 2, (96, 160))):
+            x = synth.make_images(n, hw[0], hw[1], seed=40 + n).to("cuda:0")
+            nat.check(L.rtpe_set_option(b"lanes", 0))
+            with torch.no_grad():
+                p0, r0 = model(x)
+            nat.check(L.rtpe_set_option(b"lanes", 1))
+            for rep in range(4):
+                with torch.no_grad():
+                    p1, r1 = model(x)
+                    if rep == 1:
+                        model(synth.make_images(1, 64, 96, seed=3).to("cuda:0"))        # another workspace in between
+                assert torch.equal(p0, p1) and torch.equal(r0, r1), (n, hw, rep)
+    finally:
+        nat.check(L.rtpe_set_option(b"lanes", 2))
 
 
 def test_eval_student_with_the_dual_head_student(nat, golden_dir):
