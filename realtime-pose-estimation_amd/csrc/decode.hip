@@ -351,8 +351,18 @@ __global__ void __launch_bounds__(256) nms_kernel(Map m, int h, int w, int pad, 
 // top-K, phase 1: per tile, the K best positive local maxima as sorted keys
 // ---------------------------------------------------------------------------
 template <class Map, int PAD>     // PAD >= 0: the NMS padding as a compile-time constant (divisions by PW become shifts/muls)
-__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad_rt, int K, u64* cand, int fast) {
+__global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int pad_rt, int K, u64* cand, int fast,
+                                                        int planes, int tiles) {
   const int pad = PAD >= 0 ? PAD : pad_rt;
+  // Workgroups are dealt to the 8 XCDs round robin (blockIdx.x % 8).  An XCD takes whole planes and walks their
+  // tiles in row-major order: horizontally and vertically adjacent tiles share the 128-byte lines at the edges of
+  // their source rectangles (36 floats per row of a 2x upsampled map: 2-3 lines for 1.1 lines of payload), and with
+  // (tile, plane) as the grid they were fetched once per XCD's L2 - 758 MB per batch for 279 MB of maps (PMC, round 2).
+  const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+  const int plane_l = slot / tiles;
+  const int tile = slot - plane_l * tiles;
+  const int plane = plane_l * 8 + xcd;
+  if (plane >= planes) return;                             // grid padding (whole workgroup)
   constexpr int kP = PAD >= 0 ? PAD : kMaxPad;           // the common 5x5 window needs 19 KiB of tiles, not 21.8: one more block per CU
   __shared__ __attribute__((aligned(16))) float raw[(kTH + 2 * kP) * (kTW + 2 * kP)];
   __shared__ __attribute__((aligned(16))) float rowmax[(kTH + 2 * kP) * kTW];
@@ -361,14 +371,14 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
   float* const tbuf = kFast && fast ? tbuf_s : nullptr;
   __shared__ u64 red[4];
   const int tiles_x = (w + kTW - 1) / kTW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, plane = blockIdx.y;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int y0 = ty * kTH, x0 = tx * kTW;
   __shared__ AxisTab taby, tabx;
   __shared__ u64 clist[kMaxCand];
   __shared__ int ccount, any_positive;
   if (threadIdx.x == 0) { ccount = 0; any_positive = 0; }
   if (!nms_tile(m, plane, h, w, y0, x0, pad, raw, rowmax, &taby, &tabx, &any_positive, (kTH + 2 * kP) * kTW, tbuf)) {
-    u64* outp0 = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;       // nothing positive under this tile
+    u64* outp0 = cand + ((size_t)plane * tiles + tile) * K;                 // nothing positive under this tile
     for (int r = threadIdx.x; r < K; r += 256) outp0[r] = 0;
     return;
   }
@@ -423,7 +433,7 @@ __global__ void __launch_bounds__(256) topk_tile_kernel(Map m, int h, int w, int
   }
   }
   __syncthreads();
-  u64* outp = cand + ((size_t)plane * gridDim.x + blockIdx.x) * K;
+  u64* outp = cand + ((size_t)plane * tiles + tile) * K;
   const int nc = ccount;
   if (nc <= kMaxCand) {
     // rank sort: keys are unique (the pixel index is part of the key), so the rank of a key is
@@ -1056,10 +1066,12 @@ static int topk_run(const Map& m, const TagMap& tm, int planes, int tag_shared_j
   u64* cand = reinterpret_cast<u64*>(scratch);
   // RTPE_TOPK_FAST=0: the 5x5 path without the separable sampling / register-blocked max passes (same bits)
   static const int fast = getenv("RTPE_TOPK_FAST") ? atoi(getenv("RTPE_TOPK_FAST")) : 1;
+  const size_t grid = (size_t)((planes + 7) / 8) * 8 * tiles;                     // whole planes per XCD
+  RTPE_REQUIRE(grid < 0x7fffffffu, "topk: %d planes x %d tiles do not fit one grid", planes, tiles);
   if (pad == 2)
-    hipLaunchKernelGGL((topk_tile_kernel<Map, 2>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand, fast);
+    hipLaunchKernelGGL((topk_tile_kernel<Map, 2>), dim3((unsigned)grid), dim3(256), 0, s, m, h, w, pad, K, cand, fast, planes, tiles);
   else
-    hipLaunchKernelGGL((topk_tile_kernel<Map, -1>), dim3(tiles, planes), dim3(256), 0, s, m, h, w, pad, K, cand, 0);
+    hipLaunchKernelGGL((topk_tile_kernel<Map, -1>), dim3((unsigned)grid), dim3(256), 0, s, m, h, w, pad, K, cand, 0, planes, tiles);
   RTPE_HIP_CHECK(hipGetLastError());
   size_t lds = 32 + (size_t)tiles * K * 8;
   if (lds > 150 * 1024 || tiles <= 8 * 256) lds = 32;     // the head merge (tiles <= kOwn * 256) needs no copy of the lists
