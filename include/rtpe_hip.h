@@ -208,6 +208,11 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                         int32_t N, int32_t H, int32_t W,
                         void* preds, void* refined, int32_t out_dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* the same for a program with a second input (arguments as rtpe_hrnet_forward_aux) */
+int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const void* aux_nchw_f32,
+                            int32_t N, int32_t H, int32_t W,
+                            void* preds, void* refined, int32_t out_dtype,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Process-wide tuning options; every setting gives bit-identical results (they select between kernel
  * variants for A/B measurements in one process).  "block_pc" = 0: the fused BasicBlock never runs on the
@@ -221,7 +226,9 @@ int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype,
  * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved).  "lanes" (env RTPE_LANES): the
  * independent branches of a parallel region run 0 = one after another on the caller's stream, 1 = concurrently on internal
  * streams, 2 = concurrently when the batch is small (N * H * W <= 4 * 640 * 640: the kernels of one branch cannot fill the chip;
- * default). */
+ * default).  "tile_dma" (env RTPE_TILE_DMA): the one-workgroup-per-tile conv kernel stages its halo tiles 1 = by LDS-DMA (one
+ * memory round trip per channel chunk, no staging registers; default), 0 = through registers, eight 16-byte loads per lane at a
+ * time. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */

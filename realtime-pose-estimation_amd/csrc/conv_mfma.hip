@@ -106,7 +106,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t per_tile = (uint32_t)a.n_cb * (uint32_t)(a.n_cls > 0 ? a.n_cls : 1);
   const uint32_t tq = slot / per_tile;
-  uint32_t t = tq * 8u + xcd;
+  // an XCD owns a CONTIGUOUS eighth of the row-major tile list: neighbouring tiles share their halo rows / columns and
+  // the partial 128-byte lines at their edges in one L2 (tile t on XCD t % 8 fetched them once per XCD: 1.13-1.23 x
+  // the input on the 256-channel layers, PMC round 2)
+  uint32_t t = xcd * (gridDim.x / (8u * per_tile)) + tq;
   if (t >= (uint32_t)a.N * (uint32_t)(a.tiles_x * a.tiles_y)) return;      // grid padding (whole workgroup)
   const uint32_t sub = slot - tq * per_tile;
   const int cls = (int)(sub / (uint32_t)a.n_cb);
@@ -197,6 +200,28 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     if (cci > 0) __syncthreads();
     // ---- stage the halo tile of channels [cci*cc, cci*cc+cc) ----
     const int cbase = cci * a.cc;
+    if (a.dma_stage) {
+      // LDS-DMA: a wave-instruction fills 64 consecutive 16-byte slots of the tile image (padding slots and pixels
+      // outside the image get an out-of-range offset: the bounds check writes zeros), no registers in between and
+      // ONE memory round trip per chunk however large the tile (through registers, 8 loads per lane at a time: a
+      // 17 x 17 x 64-channel tile is 9.03 of them = two round trips; 22 x 18: two; 33 x 17 x 48: two)
+      const int tile_slots = (a.halo_h * a.rowb) >> 4;
+      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xin), 0, (int)a.img_bytes, 0x00020000);
+      for (int ib = __builtin_amdgcn_readfirstlane(wv * 64); ib < tile_slots; ib += NTHREADS) {
+        const uint32_t L = (uint32_t)(ib + lane);
+        const uint32_t hy = fdiv(L, a.div_rowb16);
+        const uint32_t rem = L - hy * ((uint32_t)a.rowb >> 4);
+        const uint32_t hx = fdiv(rem, a.div_ps16);
+        const uint32_t s = rem - hx * ((uint32_t)a.pstride >> 4);
+        const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
+        const bool ok = (int)hx < a.halo_w && (int)s < slots && (unsigned)iy < (unsigned)a.H_in &&
+                        (unsigned)ix < (unsigned)a.W_in && cbase + (int)s * EPS < a.cin;
+        const uint32_t voff = ok ? (uint32_t)((iy * a.W_in + ix) * a.in_ld + cbase + (int)s * EPS) * (uint32_t)ES : 0x80000000u;
+        if (L < (uint32_t)tile_slots)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + ib * 16), 16, (int)voff, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
     // all loads of a batch are issued before the first LDS write: 8 x 16 B in flight per lane
     for (int base = 0; base < total; base += NTHREADS * 8) {
       uint4 v[8];
@@ -674,6 +699,13 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->halo_h = (t.th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   a->halo_w = (t.tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   a->rowb = conv_row_pitch(p, t.tw);
+  a->div_rowb16 = make_fastdiv((uint32_t)a->rowb >> 4);
+  a->div_ps16 = make_fastdiv((uint32_t)p.pstride >> 4);
+  {   // buffer bounds of one image of the input view for the LDS-DMA staging (the caller has set N, H_in, W_in, in_ld)
+    const int eps = 16 / p.esize;
+    a->img_bytes = (((size_t)a->H_in * a->W_in - 1) * a->in_ld + (size_t)((g.cin + eps - 1) / eps * eps)) * p.esize;
+    a->dma_stage = get_option(kOptTileDma) != 0 && a->img_bytes < 0x80000000ull ? 1 : 0;
+  }
   a->tiles_x = (a->W_pos + t.tw - 1) / t.tw;
   a->tiles_y = (a->H_pos + t.th - 1) / t.th;
   a->div_tw = make_fastdiv(t.tw);

@@ -71,9 +71,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1", "lanes", "", "", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1", "RTPE_LANES", "", "", ""};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 2, 0, 0, 0};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1", "lanes", "tile_dma", "", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "", ""};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 2, 1, 0, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -1009,16 +1009,17 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
 // passes, so each shape is measured in the cache state it will really see; the shape with
 // the smallest summed time wins for the class.  All shapes give bit-identical results.
 // Host-returning.
-extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H, int32_t W,
-                                   void* preds, void* refined, int32_t out_dtype, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+static int autotune_impl(rtpe_hrnet* h, const void* x, int32_t x_dtype, const void* aux, int32_t N, int32_t H, int32_t W,
+                         void* preds, void* refined, int32_t out_dtype, void* workspace, size_t workspace_bytes,
+                         void* stream) {
   RTPE_REQUIRE(h != nullptr, "autotune: null handle");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const auto shape = std::make_tuple(N, H, W);
   h->tuned.erase(shape);
   const size_t n_ops = h->ops.size();
   std::vector<float> ms(n_ops);
-  int rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
+  int rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops,
+               -1, -1, nullptr, nullptr, aux);
   if (rc != RTPE_OK) return rc;
 
   typedef std::tuple<int, int, int, int, int, int, int, int, int, int> Key;   // everything a launch shape depends on
@@ -1060,7 +1061,8 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
     h->tuned[shape] = trial;
     std::vector<float> best_ms(n_ops, 1e30f);
     for (int rep = 0; rep < 6; ++rep) {           // first repetition also warms caches for this choice
-      rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops);
+      rc = run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, s, ms.data(), (int)n_ops,
+               -1, -1, nullptr, nullptr, aux);
       if (rc != RTPE_OK) { h->tuned.erase(shape); return rc; }
       if (rep == 0) continue;
       for (size_t i = 0; i < n_ops; ++i) best_ms[i] = ms[i] < best_ms[i] ? ms[i] : best_ms[i];
@@ -1083,6 +1085,20 @@ extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype
   }
   h->tuned[shape] = best;
   return RTPE_OK;
+}
+
+extern "C" int rtpe_hrnet_autotune(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H, int32_t W,
+                                   void* preds, void* refined, int32_t out_dtype, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return autotune_impl(h, x, x_dtype, nullptr, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, stream);
+}
+
+// the same for a program with a second input (RTPE_OP_AUX_PACK): every timed pass is a rtpe_hrnet_forward_aux
+extern "C" int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const void* aux_nchw_f32, int32_t N,
+                                       int32_t H, int32_t W, void* preds, void* refined, int32_t out_dtype,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  RTPE_REQUIRE(aux_nchw_f32 != nullptr, "autotune_aux: the second input is null");
+  return autotune_impl(h, x, x_dtype, aux_nchw_f32, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes, stream);
 }
 
 // rtpe_hrnet_forward that also records one HIP event per op into `slot` WITHOUT

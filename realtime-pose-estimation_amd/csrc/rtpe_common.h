@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kOptLanes = 4, kNumOptions = 8 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -125,7 +125,10 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int relu, round_conv;
   FastDiv div_tw, div_slots, div_rowslots, div_cc, div_tiles_x, div_tiles_xy;
+  FastDiv div_rowb16, div_ps16;   // rowb / 16, pstride / 16 (16-byte slots of the LDS tile image)
   size_t x_bytes;        // bytes from x to the end of its tensor (buffer bounds of the LDS-DMA path)
+  size_t img_bytes;      // one-workgroup-per-tile kernel: bytes of one image of the input view (its buffer bounds)
+  int dma_stage;         // one-workgroup-per-tile kernel: 1 = the halo tiles are staged by LDS-DMA (option "tile_dma")
   int n_cb;              // cout blocks
   // several sub-launches in ONE grid (one-workgroup-per-tile kernel): the 4 sub-pixel classes of the transposed
   // conv.  Class c uses w_c[c], lo_yc/lo_xc[c], oy_c/ox_c[c]; everything else is common.  0 = a plain launch

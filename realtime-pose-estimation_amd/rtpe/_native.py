@@ -58,6 +58,8 @@ _SIGS = {
                                      POINTER(c_double), POINTER(c_double)]),
     "rtpe_hrnet_autotune": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "rtpe_hrnet_autotune_aux": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                          c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "rtpe_set_option": (c_int32, [c_char_p, c_int32]),
     "rtpe_get_option": (c_int32, [c_char_p, POINTER(c_int32)]),
     "rtpe_hrnet_tuned_ints": (c_int32, [c_void_p, POINTER(c_int32)]),

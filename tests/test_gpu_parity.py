@@ -1317,6 +1317,28 @@ def test_student_steps_vs_golden_and_oracle(nat, golden_dir):
         stu(x2.to("cuda:0"))                                   # "ATM alt is expected" (reference :993-994)
 
 
+def test_program_with_a_second_input_is_autotuned_and_keeps_its_bits(nat, golden_dir, monkeypatch):
+    """A program with an aux input (AttentionStudentSteps' alt image) tunes its launch shapes like any other
+    (rtpe_hrnet_autotune_aux: every timed pass gets the second input); tuned and default shapes give the same bits."""
+    import json
+    from rtpe.students import AttentionStudentSteps
+    shapes = json.load(open(os.path.join(golden_dir, "student_steps_shapes.json")))["shapes"]
+    sd = synth.make_state_dict({k: tuple(v) for k, v in shapes.items()}, 4, "W1")
+    x, rgb, alt = _steps_inputs()
+    outs = []
+    for tune in ("0", "1"):
+        monkeypatch.setenv("RTPE_AUTOTUNE", tune)
+        stu = AttentionStudentSteps(None, "cpu", 48, 17, 1, True, None, False).eval()
+        stu.load_state_dict(sd, strict=True)
+        stu = stu.to("cuda:0")
+        with torch.no_grad():
+            att, det = stu(x.to("cuda:0"), alt=alt.to("cuda:0"), att_divisor=20.0)
+        eng = stu._engine(torch.device("cuda:0"), ("att_divisor", 20.0))
+        assert ((x.shape[0], x.shape[2], x.shape[3]) in eng._tuned) == (tune == "1")
+        outs.append((att.cpu(), det.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_alt_colour_spaces_on_the_gpu(nat):
     """rgb2lab / rgb2hsv (what dataloaders.py:352-356 gets from scikit-image) in one HIP pass, against the float64
     restatement of the published formulas: LAB to 2e-3 of its 0...100 range (fp32 pow / cbrt), HSV to 1e-5"""

@@ -514,3 +514,25 @@ def test_alt_colour_space_restatement():
     np.testing.assert_allclose(hsv[3], [1 / 3.0, 1.0, 1.0])
     np.testing.assert_allclose(hsv[4], [2 / 3.0, 1.0, 1.0])
     np.testing.assert_allclose(hsv[5], [0.0, 0.0, 0.5])
+
+
+def test_autotune_cache_defaults_to_one_file_per_node_under_torchrun(monkeypatch):
+    """RTPE_AUTOTUNE_CACHE unset: no file in a single process, one file per node and launch (temporary directory) when
+    torch.distributed.run started several ranks on the node; an explicit value (also the empty string) wins."""
+    from rtpe.third_party import pose_higher_hrnet as ph
+    for k in ("RTPE_AUTOTUNE_CACHE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(k, raising=False)
+    assert ph._tuned_file() == ""
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert ph._tuned_file() == ""
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    a = ph._tuned_file()
+    import tempfile
+    assert a.startswith(tempfile.gettempdir()) and "29512" in a and a.endswith(".json")
+    monkeypatch.setenv("MASTER_PORT", "29513")
+    assert ph._tuned_file() != a                    # another launch, another file
+    monkeypatch.setenv("RTPE_AUTOTUNE_CACHE", "")
+    assert ph._tuned_file() == ""
+    monkeypatch.setenv("RTPE_AUTOTUNE_CACHE", "/somewhere/t.json")
+    assert ph._tuned_file() == "/somewhere/t.json"
