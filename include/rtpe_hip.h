@@ -225,8 +225,9 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * RTPE_DIRECT_1X1): the 1x1 conv kernel without a staged input tile (csrc/conv_direct.hip) is 0 = never used, 1 = one more launch
  * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved).  "lanes" (env RTPE_LANES): the
  * independent branches of a parallel region run 0 = one after another on the caller's stream, 1 = concurrently on internal
- * streams, 2 = concurrently when the batch is small (N * H * W <= 4 * 640 * 640: the kernels of one branch cannot fill the chip;
- * default).  "tile_dma" (env RTPE_TILE_DMA): the one-workgroup-per-tile conv kernel stages its halo tiles 1 = by LDS-DMA (one
+ * (normal-priority) streams that fork from and join the caller's stream (default: batch 1 at 640 x 640 2.93 -> 2.73 ms, batch
+ * 32 14.5 -> 13.7 ms per forward), 2 = concurrently when the batch is small (N * H * W <= 4 * 640 * 640).  Measured caveat: while
+ * other work of the process runs on a HIGH-priority stream the lanes more than halve the throughput; use 0 there.  "tile_dma" (env RTPE_TILE_DMA): the one-workgroup-per-tile conv kernel stages its halo tiles 1 = by LDS-DMA (one
  * memory round trip per channel chunk, no staging registers; default), 0 = through registers, eight 16-byte loads per lane at a
  * time. */
 int rtpe_set_option(const char* name, int32_t value);

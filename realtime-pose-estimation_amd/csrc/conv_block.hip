@@ -1203,7 +1203,8 @@ int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y,
   static const int abl = RTPE_DIAG_ENV_INT("RTPE_BLOCK_ABL", 0);
   a.ablate = abl;
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
-  long G = 32;                                            // one workgroup per CU
+  static const int g_env = env_int("RTPE_PERSIST_G", 32);
+  long G = g_env;                                         // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
   if (pc)
 #ifdef RTPE_DIAG

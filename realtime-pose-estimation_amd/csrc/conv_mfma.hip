@@ -535,7 +535,8 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   if (conv_stream_lds(p, (int)buf, nb, nw) > 160 * 1024) return false;
   const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
   const long units = tiles * p.n_cb;
-  long G = 32;                                            // one workgroup per CU
+  static const int g_env = env_int("RTPE_PERSIST_G", 32);
+  long G = g_env;                                         // one workgroup per CU
   const long need = (units + 7) / 8;
   if (G > need) G = need;
   G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;

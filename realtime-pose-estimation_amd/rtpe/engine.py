@@ -142,7 +142,7 @@ class TeacherPipeline:
         stream).
 
         ``decode_stream``: ``None`` (default) = environment ``RTPE_DECODE_STREAM`` (default "side");
-        ``"side"`` puts R and T on a second, high-priority HIP stream that waits for F(k) by event: the
+        ``"side"`` puts R and T on a second HIP stream that waits for F(k) by event: the
         network's ~330 kernels per forward leave the chip partly idle at every kernel boundary (a
         persistent one-workgroup-per-CU kernel ends with its slowest workgroup), and the decode's many
         small workgroups fill those gaps instead of costing their own ~0.9 ms of stream time;
@@ -161,7 +161,12 @@ class TeacherPipeline:
         if mode == "side":
             side = self.__dict__.get("_decode_stream")
             if side is None:
-                side = self._decode_stream = torch.cuda.Stream(self.device, priority=-1)
+                # normal priority (RTPE_DECODE_PRIORITY=-1: high).  A HIGH-priority decode stream beside the
+                # forward's internal lane streams (option "lanes") more than halves the throughput - batch 1:
+                # 123 img/s against 327, batch 32 with lanes on: 1,481 against 2,117 (profiles/r03_lanes_decode_stream.txt)
+                # - and buys nothing without them (2,154 against 2,149)
+                side = self._decode_stream = torch.cuda.Stream(
+                    self.device, priority=int(os.environ.get("RTPE_DECODE_PRIORITY", "0")))
         topk_done = None      # batch k-1: top-k enqueued
         refine_done = None    # batch k-2: refine enqueued
         P = self.parser

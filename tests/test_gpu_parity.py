@@ -1602,7 +1602,7 @@ def test_plane_major_inner_tensors_do_not_change_the_network_output(nat, teacher
 
 def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat, teacher, tmp_path):
     """two implementations of the same arithmetic: the product configuration (streaming kernel, fused 48-channel
-    blocks, plane-major inner tensors, direct 1x1 kernel, parallel lanes at this small batch) and a second process
+    blocks, plane-major inner tensors, direct 1x1 kernel, parallel lanes) and a second process
     that runs every conv on the one-workgroup-per-tile kernel with NHWC tensors, one op after another, must give the
     SAME bits on a large non-square batch (416x960: partial tiles on both
     axes, many units per persistent workgroup)"""
@@ -1638,7 +1638,7 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
 
 def test_parallel_lanes_do_not_change_the_network_output(nat, teacher, w48_shapes):
     """the branches of a HighResolutionModule (and the conversion convs of its fuse layers) run on internal streams that
-    fork from / join into the caller's stream (option "lanes": default at small batches): the outputs must be the bits of
+    fork from / join into the caller's stream (option "lanes": the default): the outputs must be the bits of
     the one-op-after-another run - half wrapper and fp32, odd sizes, repeated (a missing dependency would be a race:
     each configuration runs four times and every run must agree), also with the workspace of another shape in between"""
     from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
@@ -1661,7 +1661,7 @@ def test_parallel_lanes_do_not_change_the_network_output(nat, teacher, w48_shape
                         model(synth.make_images(1, 64, 96, seed=3).to("cuda:0"))        # another workspace in between
                 assert torch.equal(p0, p1) and torch.equal(r0, r1), (n, hw, rep)
     finally:
-        nat.check(L.rtpe_set_option(b"lanes", 2))
+        nat.check(L.rtpe_set_option(b"lanes", 1))
 
 
 def test_eval_student_with_the_dual_head_student(nat, golden_dir):
