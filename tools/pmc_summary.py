@@ -81,6 +81,7 @@ def load(path, keep_forwards=6, drop_last=3, raw_out=None):
         for k, v in d["c"].items():
             o[k].append(v)
         o["_us"].append((d["t1"] - d["t0"]) / 1e3)
+        o["_grid"] = [d["grid"]]
     return out
 
 
@@ -106,7 +107,7 @@ def main():
         n = len(c.get("FETCH_SIZE", c.get("_us_profiled", [])))
         e = {"grid": grid, "launches_per_pass": n}
         if isinstance(grid, str):
-            e["grid"] = 114688
+            e["grid"] = int(c["_grid"][0])               # the launch's real grid size (threads), as in the raw rows
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             e["fetch_bytes"] = mean(c["FETCH_SIZE"]) * 1024 * 2
             e["write_bytes"] = mean(c["WRITE_SIZE"]) * 1024
