@@ -335,7 +335,9 @@ def main():
             # per-op events for the first n_slots timed steps only (their markers cost launch gaps)
             return eng.forward_record(xb, k) if record and k < n_slots else eng.forward(xb)
         last = None
-        for res in pipe.stream((xs[k % len(xs)] for k in range(k_steps)), (S, S), on_forward=fwd):
+        # the recorded steps run alone (no other forward in flight): their per-op events time each kernel by itself
+        for res in pipe.stream((xs[k % len(xs)] for k in range(k_steps)), (S, S), on_forward=fwd,
+                               exclusive=(lambda k: record and k < n_slots)):
             people[0] = sum(len(p) if p.ndim == 3 else 0 for p, _ in res)
             last = pipe.gather(ids, res, equal_counts=True)
         return last
@@ -520,6 +522,9 @@ def main():
         "config": {"workload": "configs[2]: batch=%d per GPU, %dx%d, half-wrapper teacher forward + decode of "
                                "17 keypoint channels, weights %s (seeded random)" % (B, S, S, args.weights),
                    "batch_per_gpu": B, "people_per_batch_rank0": people[0],
+                   "pipeline": "software-pipelined steps (TeacherPipeline.stream): %s forward(s) in flight on internal streams, "
+                               "decode of batch k-1 beside forward k; the %d recorded steps run alone" % (
+                                   os.environ.get("RTPE_FORWARDS_IN_FLIGHT", "2"), n_slots),
                    "forward_only_images_per_sec_per_gpu": round(B / fwd_s, 1)},
         "roofline": roofline, "roofline_time_dominant": td, "cpu_baseline": cpu,
     }

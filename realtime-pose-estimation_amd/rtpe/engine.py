@@ -133,7 +133,7 @@ class TeacherPipeline:
         hw = tuple(out_hw) if out_hw is not None else tuple(images.shape[2:])
         return self.parser.parse_lowres(refined, preds[:, NUM_HEATMAPS:], hw)
 
-    def stream(self, batches, out_hw=None, on_forward=None, decode_stream=None):
+    def stream(self, batches, out_hw=None, on_forward=None, decode_stream=None, in_flight=None, exclusive=None):
         """Software-pipelined loop over an iterable of (N,3,H,W) GPU batches, in the order
         F(k) R(k-1) T(k)  (forward, adjust+refine of the previous batch, fused top-k).  The host part
         of the decode of batch k-1 (tag matching on the host cores) runs while the GPU executes F(k),
@@ -148,6 +148,15 @@ class TeacherPipeline:
         small workgroups fill those gaps instead of costing their own ~0.9 ms of stream time;
         ``"same"`` keeps everything on the current stream.
 
+        ``in_flight`` (default: environment ``RTPE_FORWARDS_IN_FLIGHT``, default 2): forwards of consecutive batches
+        alternate between that many internal HIP streams, each with an activation workspace of its own, so that the
+        low-occupancy layers of one batch (stem, layer1, transitions, heads: HBM- and latency-bound) run beside the
+        matrix-bound stages of the other - 14.5 -> 13.0-13.4 ms per forward at batch 32, 3.30 -> 2.13 ms at batch 1
+        (`tools/two_stream_probe.py`).  Inside this loop the executor's parallel lanes are switched off (both at once are
+        slower than either).  1 = every forward on the caller's stream.  ``exclusive(k)`` true: the forward of batch k
+        runs alone - it starts when the forwards in flight are done and the next one starts behind it (bench.py times the
+        kernels of such a step with per-op events: a kernel's duration beside another forward is not its own).
+
         Yields one ``[(people, scores)] * N`` list per batch, in order, two steps after the batch
         was submitted.  ``on_forward(k, x)`` may replace the plain forward (bench.py records op
         events).  Keep the host thread pools small (``torch.set_num_threads``): a burst of idle-
@@ -157,6 +166,22 @@ class TeacherPipeline:
         if mode not in ("side", "same"):
             raise ValueError("decode_stream must be 'side' or 'same', not %r" % (mode,))
         main = torch.cuda.current_stream(self.device)
+        n_fwd = int(in_flight if in_flight is not None else os.environ.get("RTPE_FORWARDS_IN_FLIGHT", "2"))
+        if n_fwd < 1 or n_fwd > 4:
+            raise ValueError("in_flight must be 1..4, not %r" % (n_fwd,))
+        fwd_streams = None
+        lanes_before = None
+        if n_fwd > 1:
+            fwd_streams = self.__dict__.get("_forward_streams")
+            if fwd_streams is None or len(fwd_streams) < n_fwd:
+                fwd_streams = self._forward_streams = [torch.cuda.Stream(self.device) for _ in range(n_fwd)]
+            from . import _native as nat
+            from .third_party.pose_higher_hrnet import set_workspace_slot
+            import ctypes
+            v = ctypes.c_int32()
+            nat.check(nat.lib().rtpe_get_option(b"lanes", ctypes.byref(v)))
+            lanes_before = v.value
+            nat.check(nat.lib().rtpe_set_option(b"lanes", 0))
         side = None
         if mode == "side":
             side = self.__dict__.get("_decode_stream")
@@ -167,6 +192,7 @@ class TeacherPipeline:
                 # - and buys nothing without them (2,154 against 2,149)
                 side = self._decode_stream = torch.cuda.Stream(
                     self.device, priority=int(os.environ.get("RTPE_DECODE_PRIORITY", "0")))
+        after_alone = None    # the stream of an exclusive forward that the next forward has to wait for
         topk_done = None      # batch k-1: top-k enqueued
         refine_done = None    # batch k-2: refine enqueued
         P = self.parser
@@ -186,12 +212,35 @@ class TeacherPipeline:
         try:
             with torch.no_grad():
                 for k, x in enumerate(batches):
-                    preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
+                    fs = main
+                    if fwd_streams is not None:
+                        # forward k on stream k % n with workspace slot 1 + k % n; the input was produced on `main`
+                        fs = fwd_streams[k % n_fwd]
+                        fs.wait_stream(main)
+                        alone = exclusive is not None and bool(exclusive(k))
+                        if alone or after_alone is not None:
+                            for other in fwd_streams[:n_fwd]:
+                                if other is not fs:
+                                    fs.wait_stream(other)
+                        after_alone = fs if alone else None
+                        x.record_stream(fs)
+                        prev_slot = set_workspace_slot(1 + k % n_fwd)
+                        try:
+                            with torch.cuda.stream(fs):
+                                preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
+                        finally:
+                            set_workspace_slot(prev_slot)
+                    else:
+                        preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
                     hw = tuple(out_hw) if out_hw is not None else tuple(x.shape[2:])
                     f_done = None
-                    if side is not None:
+                    if side is not None or fs is not main:
                         f_done = torch.cuda.Event()
-                        f_done.record(main)
+                        f_done.record(fs)
+                        if side is None:
+                            main.wait_event(f_done)          # the decode runs on the caller's stream
+                            preds.record_stream(main)
+                            refined.record_stream(main)
                     if topk_done is not None:
                         on_decode_stream(P.lowres_match, topk_done)     # host matching overlaps F(k) on the GPU
                     st = on_decode_stream(P.lowres_topk, refined, preds[:, NUM_HEATMAPS:], hw, after=f_done,
@@ -210,6 +259,10 @@ class TeacherPipeline:
             # sees the decode as done
             if side is not None:
                 main.wait_stream(side)
+            if fwd_streams is not None:
+                for fs in fwd_streams[:n_fwd]:
+                    main.wait_stream(fs)
+                nat.check(nat.lib().rtpe_set_option(b"lanes", lanes_before))
 
     def gather(self, image_ids, results, equal_counts=False):
         """all-gather of the decoded keypoints over the process group (RCCL).  ``equal_counts``:

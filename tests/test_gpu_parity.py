@@ -585,22 +585,33 @@ def test_pipeline_on_small_and_odd_batches(nat, teacher, hw, n):
 
 
 def test_pipelined_stream_equals_batch_by_batch(nat, teacher):
-    """TeacherPipeline.stream keeps three batches in flight on one stream (forward of batch k, refine of k-1,
-    top-k of k) with tables in recycled pinned buffers: five DIFFERENT batches must decode exactly as they do one
-    at a time, in order"""
+    """TeacherPipeline.stream keeps three batches in flight (forward of batch k, refine of k-1, top-k of k; since
+    round 3 also the forwards of two consecutive batches on two streams) with tables in recycled pinned buffers: five
+    DIFFERENT batches must decode exactly as they do one at a time, in order"""
     from rtpe.engine import TeacherPipeline
     m, sd = teacher("W0")
     pipe = TeacherPipeline(m, device="cuda:0")
     batches = [synth.make_images(3, 128, 160, seed=50 + k).to("cuda:0") for k in range(5)]
     want = [pipe(b) for b in batches]
-    got = list(pipe.stream(iter(batches)))
-    assert len(got) == len(want)
-    for k in range(len(want)):
-        assert len(got[k]) == len(want[k]) == 3
-        for (gp, gs), (wp, ws) in zip(got[k], want[k]):
-            np.testing.assert_array_equal(gp, wp)
-            np.testing.assert_array_equal(np.array(gs, np.float32), np.array(ws, np.float32))
+    # default (two forwards in flight on internal streams, each with its own workspace), one at a time on the caller's
+    # stream, three in flight with an exclusive step in the middle, and everything on one stream
+    runs = [dict(), dict(in_flight=1), dict(in_flight=3, exclusive=lambda k: k == 2),
+            dict(in_flight=2, decode_stream="same"), dict(in_flight=1, decode_stream="same")]
+    for kw in runs:
+        got = list(pipe.stream(iter(batches), **kw))
+        assert len(got) == len(want)
+        for k in range(len(want)):
+            assert len(got[k]) == len(want[k]) == 3
+            for (gp, gs), (wp, ws) in zip(got[k], want[k]):
+                np.testing.assert_array_equal(gp, wp)
+                np.testing.assert_array_equal(np.array(gs, np.float32), np.array(ws, np.float32))
     assert sum(len(p) for r in want for p, _ in r) > 0
+    # the loop leaves the process-wide settings as it found them
+    v = ctypes.c_int32()
+    nat.check(nat.lib().rtpe_get_option(b"lanes", ctypes.byref(v)))
+    assert v.value == 1
+    from rtpe.third_party.pose_higher_hrnet import set_workspace_slot
+    assert set_workspace_slot(0) == 0
 
 
 def test_forward_as_close_to_exact_as_the_cpu_half_path(nat, teacher):

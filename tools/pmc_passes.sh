@@ -14,10 +14,12 @@ export RTPE_AUTOTUNE_CACHE=$PWD/$OUT/autotune.json
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
 python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 echo "unprofiled: $(cut -c1-120 $OUT/bench_unprofiled.json)"
-# the profiled passes run the branches of a module one after another (option "lanes" off): with the lanes on, kernels of
+# the profiled passes run one forward at a time with the branches of a module one after another (option "lanes" off,
+# RTPE_FORWARDS_IN_FLIGHT=1): with the lanes on or two forwards in flight, kernels of
 # different branches overlap in time and a kernel's duration in the trace is not its own (bench.py times the roofline
 # kernel on single-stream recorded steps for the same reason)
 export RTPE_LANES=0
+export RTPE_FORWARDS_IN_FLIGHT=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > $OUT/bench_traced.json 2> $OUT/bench_traced.err
 echo "traced: $(cut -c1-120 $OUT/bench_traced.json)"
 run_pass () {
