@@ -3,6 +3,7 @@
 // kernels of conv_mfma.hip / elementwise.hip.  Owns only the packed weights.
 #include <stdarg.h>
 
+#include <chrono>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -409,6 +410,20 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
                int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
                std::vector<hipEvent_t>* rec = nullptr, const void* aux = nullptr) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
+  static const int host_prof = env_int("RTPE_HOST_PROF", 0);       // host time of a forward: where it goes (stderr)
+  typedef std::chrono::steady_clock hclock;
+  const hclock::time_point hp0 = hclock::now();
+  double hp_launch = 0.0;
+#define RTPE_HP_LAUNCH(stmt)                                                                   \
+  do {                                                                                         \
+    if (host_prof) {                                                                           \
+      const hclock::time_point t_ = hclock::now();                                             \
+      stmt;                                                                                    \
+      hp_launch += std::chrono::duration<double, std::micro>(hclock::now() - t_).count();      \
+    } else {                                                                                   \
+      stmt;                                                                                    \
+    }                                                                                          \
+  } while (0)
   // kernels, events and function attributes act on HIP's CURRENT device: make the handle's device current for
   // the call (the stream and every buffer must belong to it) and give the caller's device back afterwards
   DeviceGuard guard(h->device);
@@ -511,7 +526,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.y = tptr(d.out_t, d.out_coff);
       a.N = N; a.H = H; a.W = W; a.out_ld = to.channels;
       a.f32 = (d.flags & RTPE_F_F32) ? 1 : 0;
-      rc = stem_launch(a, s);
+      RTPE_HP_LAUNCH(rc = stem_launch(a, s));
     } else if (d.kind == RTPE_OP_CONV && o.fuse == 2 && force == nullptr && only_op < 0 &&
                conv_block_supports(d.cin, d.cout, H >> h->tensors[d.in_t].ds_log2, W >> h->tensors[d.in_t].ds_log2)) {
       // second conv of a fused BasicBlock: done by the launch of its head (same test as there: a map too
@@ -521,13 +536,13 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       const rtpe_tensor_desc& ti = h->tensors[d.in_t];
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
       const OpState& o2 = h->ops[i + 1];
-      rc = conv_block_launch(tptr(d.in_t, d.in_coff), ti.channels,
+      RTPE_HP_LAUNCH(rc = conv_block_launch(tptr(d.in_t, d.in_coff), ti.channels,
                              ((size_t)N * Hi * Wi * ti.channels - (size_t)d.in_coff) * 2,
                              tptr(o2.d.out_t, o2.d.out_coff), h->tensors[o2.d.out_t].channels,
                              reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[0]),
                              reinterpret_cast<const float*>(h->arena + o.ab_dev_off),
                              reinterpret_cast<const _Float16*>(h->arena + o2.w_dev_off[0]),
-                             reinterpret_cast<const float*>(h->arena + o2.ab_dev_off), N, Hi, Wi, s);
+                             reinterpret_cast<const float*>(h->arena + o2.ab_dev_off), N, Hi, Wi, s));
     } else if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
       const rtpe_tensor_desc& ti = h->tensors[d.in_t];
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
@@ -614,10 +629,10 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           merged.w_c[k] = a.w;
           merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
           merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
-          if (k == o.n_geom - 1) rc = conv_launch(o.plan[0], merged_tile, merged, s);
+          if (k == o.n_geom - 1) RTPE_HP_LAUNCH(rc = conv_launch(o.plan[0], merged_tile, merged, s));
           continue;
         }
-        rc = conv_launch(o.plan[k], tile, a, s);
+        RTPE_HP_LAUNCH(rc = conv_launch(o.plan[k], tile, a, s));
       }
     } else if (d.kind == RTPE_OP_AUX_PACK) {
       if (aux == nullptr) { set_error("forward: this program has a second input (use rtpe_hrnet_forward_aux)"); return RTPE_E_INVALID; }
@@ -687,7 +702,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.N = N; a.H = H >> to.ds_log2; a.W = W >> to.ds_log2;
       a.f32 = (d.flags & RTPE_F_F32) ? 1 : 0;
       a.relu = (d.flags & RTPE_F_RELU) ? 1 : 0;
-      rc = fuse_launch(a, s);
+      RTPE_HP_LAUNCH(rc = fuse_launch(a, s));
     }
     if (rc != RTPE_OK) return rc;
     if (lanes_on && cur_region > 0 && h->needs_event[i]) RTPE_HIP_CHECK(hipEventRecord(h->op_event[i], s));
@@ -696,6 +711,17 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     if (rec && has_event) RTPE_HIP_CHECK(hipEventRecord((*rec)[i + 1], s));
   }
   if (lanes_on && cur_region > 0) RTPE_HIP_CHECK(join_lanes());
+  if (host_prof) {
+    static double sum_total = 0.0, sum_launch = 0.0;
+    static int n_calls = 0;
+    sum_total += std::chrono::duration<double, std::micro>(hclock::now() - hp0).count();
+    sum_launch += hp_launch;
+    if (++n_calls % host_prof == 0) {
+      fprintf(stderr, "rtpe host profile (N=%d, %zu ops, lanes %d): %.0f us per forward on the host, %.0f us of it inside the kernel "
+              "launch helpers (mean of %d calls)\n", N, h->ops.size(), (int)lanes_on, sum_total / n_calls, sum_launch / n_calls, n_calls);
+    }
+  }
+#undef RTPE_HP_LAUNCH
   if (timed) {
     RTPE_HIP_CHECK(hipEventSynchronize(ev.back()));
     const int rc2 = read_op_times(h, ev, force == nullptr && only_op < 0, op_ms);
