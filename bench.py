@@ -232,6 +232,20 @@ def run_other_config(args, dev):
             res = step()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        # the same work through the pipelined loop (TeacherPipeline.stream: two forwards in flight, decode of image
+        # k-1 beside forward k) - what a caller gets who feeds the images as a stream instead of one at a time
+        piped = None
+        if args.config == 1:
+            pipe = engine.TeacherPipeline(net, device=dev)
+            for _ in pipe.stream((x for _ in range(4)), (S, S)):
+                pass
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            n_p = 0
+            for _ in pipe.stream((x for _ in range(2 * args.steps)), (S, S)):
+                n_p += 1
+            torch.cuda.synchronize(dev)
+            piped = round(B * n_p / (time.perf_counter() - t1), 2)
         # forward alone, per-op events
         fwd = None
         roof = None
@@ -256,7 +270,8 @@ def run_other_config(args, dev):
         "metric": "images/sec at %dx%d (%s)" % (S, S, "HRNet-w48 fwd+decode" if args.config == 1 else "AttentionStudent fwd+decode"),
         "value": round(B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype, "data": "synthetic", "config": {"workload": name, "batch_per_gpu": B, "people_last_step": people},
+        "dtype": dtype, "data": "synthetic", "config": dict({"workload": name, "batch_per_gpu": B, "people_last_step": people},
+                                                             **({"pipelined_images_per_sec": piped} if piped is not None else {})),
         "roofline": roof, "cpu_baseline": None}))
 
 

@@ -505,6 +505,10 @@ static const TileCand kCands[] = {
     {4, 2, 8, 16},  {4, 2, 16, 8},  {5, 5, 20, 20}, {5, 5, 10, 40}, {5, 5, 40, 10},
     {4, 5, 16, 20}, {4, 5, 20, 16}, {4, 5, 8, 40},  {4, 5, 40, 8},
     {4, 1, 8, 8},                                    // stride-2 convs: a 17 x 17 halo tile, 2-3 workgroups per CU
+    // the same 8 x 8 tile on 2 waves x 2 / 1 wave x 4 pixel tiles: every wave of a workgroup fetches ALL weight
+    // fragments of the cout block through L1 (4 waves x MT KiB per k-step - 24 KiB for 96 MFMA cycles at MT = 6);
+    // fewer waves with more pixel tiles each fetch them once / twice per 64 pixels
+    {2, 2, 8, 8}, {1, 4, 8, 8},
 };
 
 static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
@@ -519,7 +523,7 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
                         bool allow_resident = true) {
   // stride 1: 4 or 5 pixel tiles per wave; stride 2 (4x the halo per output pixel): 2, and only with
   // resident weights (the halo buffers leave no room for the weight ring)
-  if (!conv_stream_supports(p)) return false;
+  if (!conv_stream_supports(p) || c.waves < 4) return false;
   if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != 2 || p.n_cchunks != 1)) return false;
   const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
   if (hw * 6 > 256) return false;                        // a halo row is at most 4 DMA instructions
@@ -665,7 +669,7 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;  // 128 accumulators + operands: keep 2 waves/SIMD
     if (p.mt == 6 && c.nt > 2) continue;   // the 96-cout variant exists for 1 and 2 pixel tiles per wave
-    if (c.nt == 1) continue;               // 8 x 8 tiles are autotuning candidates of stride-2 convs only
+    if (c.nt == 1 || c.waves < 4) continue;  // 8 x 8 tiles are autotuning candidates of stride-2 convs only
     if (force_nt && c.nt != force_nt) continue;
     if (force_waves && c.waves != force_waves) continue;
     const size_t lds = tile_lds(p, c.th, c.tw, c.waves, c.nt);
@@ -750,15 +754,15 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
   out->clear();
   double min_waste = 1e30;
   for (const TileCand& c : kCands) {
-    if (c.nt == 1 && (p.in_mul != 2 || p.mt < 3)) continue;
+    if ((c.nt == 1 || c.waves < 4) && (p.in_mul != 2 || p.mt < 3)) continue;
     const double w = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                      ((double)H_pos * W_pos);
     if (w < min_waste) min_waste = w;
   }
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;
-    if (p.mt == 6 && c.nt > 2) continue;
-    if (c.nt == 1 && (p.in_mul != 2 || p.mt < 3)) continue;
+    if (p.mt == 6 && c.nt > 2 && c.waves >= 4) continue;
+    if ((c.nt == 1 || c.waves < 4) && (p.in_mul != 2 || p.mt < 3)) continue;
     const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                          ((double)H_pos * W_pos);
     // (small maps - 20 x 20 at /32 - fit one 20 x 20 tile per image: 32 workgroups for 256 CUs.  Smaller tiles
@@ -826,6 +830,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5) RTPE_V(6, 2, 4)
   RTPE_V(2, 8, 4) RTPE_V(2, 4, 4) RTPE_V(2, 2, 4) RTPE_V(2, 5, 4) RTPE_V(2, 5, 5)
   RTPE_V(1, 8, 4) RTPE_V(1, 4, 4) RTPE_V(1, 2, 4) RTPE_V(1, 5, 4) RTPE_V(1, 5, 5)
+  RTPE_V(6, 2, 2) RTPE_V(6, 4, 1) RTPE_V(4, 2, 2) RTPE_V(4, 4, 1) RTPE_V(3, 2, 2) RTPE_V(3, 4, 1)
 #undef RTPE_V
   set_error("conv: no kernel variant mt=%d nt=%d waves=%d", p.mt, t.nt, t.waves);
   return RTPE_E_INVALID;

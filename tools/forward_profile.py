@@ -22,8 +22,12 @@ def main():
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 640
     out = sys.argv[3] if len(sys.argv) > 3 else None
     torch.manual_seed(0)
-    model = build_hrnet_w48_teacher().to("cuda:0")
-    net = model[1]
+    if os.environ.get("RTPE_PROFILE_FP32", "0") == "1":         # configs[1]: the fp32 network without the half wrapper
+        from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+        model = net = PoseHigherResolutionNet().to("cuda:0").eval()
+    else:
+        model = build_hrnet_w48_teacher().to("cuda:0")
+        net = model[1]
     x = torch.randn(B, 3, S, S, device="cuda:0")
     with torch.no_grad():
         model(x)
