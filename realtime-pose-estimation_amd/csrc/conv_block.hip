@@ -996,7 +996,7 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
 
   // ========== consumers: x-tile requests; BN2 + x + ReLU + stores of unit i-2; conv2 (weights in registers) of unit i-1 ==========
   const int cw = wv - 4;                                   // output rows 2 cw, 2 cw + 1 of the tile
-  // prologue: conv1's weights into LDS (a quarter per consumer wave), BN2 parameters, x tiles 0 and 1
+  // prologue: conv1's weights into LDS (a quarter per consumer wave), BN2 parameters, this wave's part of x tile 0
   {
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w1), 0, 2 * kWSlot, 0x00020000);
     const int voff = lane * 16;
@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
     xoffr[it] = (uint32_t)(((pw >> 4) * a.W + (pw & 15)) * a.in_ld * 2 + slot * 16);
     yoffr[it] = (uint32_t)(((pw >> 4) * a.W + (pw & 15)) * a.out_ld * 2 + slot * 16);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // W1, BN2, both x tiles, w2 registers
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's prologue requests: its quarter of W1, BN2, its part of x tile 0, its w2 registers
   // tell the compiler too: otherwise it keeps the 42 loads "pending" at the loop header and counts them down
   // with s_waitcnt vmcnt(N) inside the k loop - N so small for the last ones that the wait would also cover the
   // x-tile requests issued a moment earlier
