@@ -56,9 +56,10 @@ def main():
             for o in out[:40]:
                 print("%-60s wg %5s vgpr %5s n=%-5s total %11s mean %9s median %9s min %9s %6s" % o)
             if a.csv:
-                with open(a.csv, "w") as f:
+                with open(a.csv, "w", newline="") as f:
+                    wr = csv.writer(f)              # kernel names contain commas (template arguments): quoted
                     for o in out:
-                        f.write(",".join(str(x) for x in o) + "\n")
+                        wr.writerow(o)
 
 
 if __name__ == "__main__":
