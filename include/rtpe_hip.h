@@ -110,6 +110,12 @@ int rtpe_device_count(void);
 #define RTPE_F_F32 32        /* the op works on fp32 tensors / weights (plain
                                PoseHigherResolutionNet without the half
                                wrapper; the students' fp32 part)              */
+#define RTPE_F_PAIR_HEAD 64  /* conv 1x1 64 -> 256 + residual + ReLU whose output the NEXT op, a conv 1x1
+                                256 -> 64 + ReLU flagged RTPE_F_PAIR_TAIL, reads: the two may run as one
+                                kernel that writes the 256-channel tensor and never reads it back (layer1's
+                                Bottlenecks, pose_higher_hrnet.py:96-116; option "pair_1x1").  The program's
+                                slot assignment must keep the head's input and residual alive over the tail */
+#define RTPE_F_PAIR_TAIL 128
 
 typedef struct rtpe_tensor_desc {
   int32_t channels; /* allocated channels per pixel (the NHWC row length)     */
@@ -229,7 +235,8 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * 32 14.5 -> 13.7 ms per forward), 2 = concurrently when the batch is small (N * H * W <= 4 * 640 * 640).  Measured caveat: while
  * other work of the process runs on a HIGH-priority stream the lanes more than halve the throughput; use 0 there.  "tile_dma" (env RTPE_TILE_DMA): the one-workgroup-per-tile conv kernel stages its halo tiles 1 = by LDS-DMA (one
  * memory round trip per channel chunk, no staging registers; default), 0 = through registers, eight 16-byte loads per lane at a
- * time. */
+ * time.  "pair_1x1" (env RTPE_PAIR_1X1): op pairs flagged RTPE_F_PAIR_HEAD / _TAIL run 1 = as one kernel (csrc/conv_pair.hip;
+ * default), 0 = as two launches. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */

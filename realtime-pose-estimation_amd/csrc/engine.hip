@@ -36,6 +36,7 @@ struct OpState {
   size_t ab_dev_off;    // alpha then beta, fp32[cout_pad]
   int n_geom;
   int fuse;             // 1: head of a fused BasicBlock (this conv + the next run as one kernel), 2: its second conv
+  int pair;             // 1: head of a 1x1 pair (conv_pair.hip: launched with the next op), 2: its tail
 };
 
 }  // namespace rtpe
@@ -72,9 +73,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1", "lanes", "tile_dma", "", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "", ""};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 0, 0};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1", "lanes", "tile_dma", "pair_1x1", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", ""};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -218,6 +219,23 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     if (other_reader) continue;
     a1.fuse = 1;
     a2.fuse = 2;
+  }
+  // 1x1 pairs (conv_pair.hip): the flags are the program's promise that the head's input and residual stay alive over the
+  // tail; whether the two ops ARE such a pair is checked here (anything else: the flags are ignored)
+  for (OpState& o : h->ops) o.pair = 0;
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    OpState& a1 = h->ops[i];
+    if (!(a1.d.flags & RTPE_F_PAIR_HEAD) || i + 1 >= h->ops.size()) continue;
+    const rtpe_op_desc &d1 = a1.d, &d2 = h->ops[i + 1].d;
+    const int want1 = RTPE_F_RELU | RTPE_F_ROUND_CONV | RTPE_F_PAIR_HEAD, want2 = RTPE_F_RELU | RTPE_F_ROUND_CONV | RTPE_F_PAIR_TAIL;
+    if (d1.kind != RTPE_OP_CONV || d2.kind != RTPE_OP_CONV || d1.flags != want1 || d2.flags != want2 || d1.ksize != 1 ||
+        d2.ksize != 1 || d1.stride != 1 || d2.stride != 1 || d1.res_t < 0 || d2.res_t >= 0 || d2.in_t != d1.out_t ||
+        d2.in_coff != d1.out_coff || d2.cin != d1.cout || !conv_pair_supports(d1.cin, d1.cout, d2.cout) ||
+        h->tensors[d1.in_t].reserved == 4 || d1.reserved[2] > 0 || d2.reserved[2] > 0 || d2.out_t == d1.in_t ||
+        d2.out_t == d1.res_t || d2.out_t == d1.out_t)
+      continue;
+    a1.pair = 1;
+    h->ops[i + 1].pair = 2;
   }
   h->arena_bytes = off;
   {
@@ -481,6 +499,10 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
     for (size_t l = 0; l < 4; ++l) RTPE_HIP_CHECK(hipEventCreateWithFlags(&h->op_event[h->ops.size() + l], hipEventDisableTiming));
     RTPE_HIP_CHECK(hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming));
   }
+  // 1x1 pairs run as one kernel in whole forwards only (timed / recorded ones included: the pair's time is the tail's)
+  const bool pairs_on = get_option(kOptPair1x1) != 0 && only_op < 0 && force == nullptr;
+  ConvArgs pair_args;
+  memset(&pair_args, 0, sizeof(pair_args));
   int cur_region = 0;
   bool lane_used[4] = {false, false, false, false};
   auto join_lanes = [&]() -> hipError_t {
@@ -630,6 +652,14 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
           merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
           if (k == o.n_geom - 1) RTPE_HP_LAUNCH(rc = conv_launch(o.plan[0], merged_tile, merged, s));
+          continue;
+        }
+        if (pairs_on && o.pair == 1) {                    // launched together with the next op (conv_pair.hip)
+          pair_args = a;
+          continue;
+        }
+        if (pairs_on && o.pair == 2) {
+          RTPE_HP_LAUNCH(rc = conv_pair_launch(h->ops[i - 1].plan[0], pair_args, o.plan[0], a, s));
           continue;
         }
         RTPE_HP_LAUNCH(rc = conv_launch(o.plan[k], tile, a, s));
@@ -1017,6 +1047,11 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
   {
     auto it = h->tuned.find(std::make_tuple(N, H, W));
     if (it != h->tuned.end() && it->second[op * 4].nt) t = it->second[op * 4];
+  }
+  if (o.pair && get_option(kOptPair1x1) != 0) {     // 1x1 pair (conv_pair.hip): 16-pixel tiles per wave, 8 waves
+    out8[0] = o.pair == 1 ? 16 : 4; out8[1] = 1; out8[2] = 8; out8[3] = 1; out8[4] = 16; out8[5] = o.pair == 1 ? 64 : 256; out8[6] = 1;
+    out8[7] = o.pair == 1 ? -800001 : -800002;
+    return RTPE_OK;
   }
   if (o.fuse) {                      // fused BasicBlock (conv_block.hip): 6x32 tiles, 5 + 3 pixel tiles per wave
     out8[0] = 3; out8[1] = o.fuse == 1 ? 5 : 3; out8[2] = 4; out8[3] = 6; out8[4] = 32; out8[5] = 48; out8[6] = 1;

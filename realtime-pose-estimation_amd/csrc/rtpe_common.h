@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kNumOptions = 8 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -193,6 +193,9 @@ bool conv_stream2_drain_fits(int mt, int nt, int halo_h, int halo_w, bool reside
 int conv_stream2_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 // 1x1 convs without a staged tile (conv_direct.hip, ConvTile::kind == 4): B fragments straight from global memory,
 // weights in registers; conv_direct_mb = cout tiles per wave, 0 when the layer is not one the kernel takes
+// conv 1x1 64 -> 256 + residual + ReLU and the conv 1x1 256 -> 64 + ReLU that reads its output, as one kernel (conv_pair.hip)
+bool conv_pair_supports(int cin1, int cout1, int cout2);
+int conv_pair_launch(const ConvPlan& p1, const ConvArgs& c1, const ConvPlan& p2, const ConvArgs& c2, hipStream_t s);
 int conv_direct_mb(const ConvPlan& p);
 int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)

@@ -17,6 +17,7 @@ RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
 OP_STEM, OP_CONV, OP_DECONV, OP_FUSE, OP_CAST, OP_AVGPOOL, OP_SE, OP_CAM_COMBINE, OP_SIGMOID_ADD = range(9)
 OP_AUX_PACK, OP_RESIZE, OP_GATE_MUL = 9, 10, 11
 F_RELU, F_ROUND_CONV, F_OUT_PREDS, F_OUT_REFINED, F_NO_NHWC, F_F32 = 1, 2, 4, 8, 16, 32
+F_PAIR_HEAD, F_PAIR_TAIL = 64, 128
 
 
 class TensorDesc(Structure):

@@ -1641,10 +1641,37 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
         "np.savez(%r, p=p.cpu().numpy(), r=r.cpu().numpy())\n"
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
-    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0")
+    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
+
+
+def test_1x1_pairs_do_not_change_the_network_output(nat, teacher):
+    """conv3 + bn3 + residual + ReLU of a layer1 Bottleneck and conv1 + bn1 + ReLU of the next one (reference :96-116) run
+    as ONE kernel that never reads the 256-channel tensor back (option "pair_1x1", csrc/conv_pair.hip): the program flags
+    three such pairs, and the network's outputs are the bits of the two-launch path - odd batch sizes and a pixel count
+    that is not a multiple of the 16-pixel tiles included, repeated (the head's input and residual share no slot with
+    the tail's output)"""
+    L = nat.lib()
+    m, sd = teacher("W1")
+    prog = m[1]._engine(torch.device("cuda:0")).program
+    n_head = sum(1 for o in prog.ops if o.flags & 64)
+    n_tail = sum(1 for o in prog.ops if o.flags & 128)
+    assert n_head == n_tail == 3
+    try:
+        for n, hw in ((1, (64, 96)), (3, (160, 224)), (2, (96, 32)), (5, (128, 128))):
+            x = synth.make_images(n, hw[0], hw[1], seed=70 + n).to("cuda:0")
+            nat.check(L.rtpe_set_option(b"pair_1x1", 0))
+            with torch.no_grad():
+                p0, r0 = m(x)
+            nat.check(L.rtpe_set_option(b"pair_1x1", 1))
+            for rep in range(2):
+                with torch.no_grad():
+                    p1, r1 = m(x)
+                assert torch.equal(p0, p1) and torch.equal(r0, r1), (n, hw, rep)
+    finally:
+        nat.check(L.rtpe_set_option(b"pair_1x1", 1))
 
 
 def test_parallel_lanes_do_not_change_the_network_output(nat, teacher, w48_shapes):

@@ -54,10 +54,22 @@ def main():
         ds = eng.program.tensors[op.out_t].ds_log2 if op.out_t >= 0 else 1
         tag = ""
         if t[0]:
-            kind = (" S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else ""
+            kind = (" PAIR-HEAD (launched with the next op)" if t[7] == -800001 else " PAIR (both 1x1 convs)" if t[7] == -800002 else
+                    " S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else ""
             tag = " [m%d n%d w%d %dx%d cc%d cb%d%s]" % (tuple(t[:7]) + (kind,))
         key = "%s @/%d%s" % (nm, 1 << ds, tag)
         c = eng.op_cost(i, B, S, S)
+        if t[0] and t[7] == -800001:                      # head of a 1x1 pair: its work is done by the launch at the next op
+            pair_head = (acc[i], c[0], c[1])
+            continue
+        if t[0] and t[7] == -800002:
+            key = "pair 64->256 k1s1+res+relu, 256->64 k1s1+relu @/%d [one kernel: 8 waves x 16-pixel tiles]" % (1 << ds)
+            d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += acc[i] + pair_head[0]
+            d[2] += c[0] + pair_head[1]
+            d[3] += c[1] + pair_head[2]
+            continue
         if t[0] and t[7] == -900002:                      # second conv of a fused BasicBlock: its work belongs to the
             d = by[head_key]                              # launch of the first (time 0 here)
             d[1] += acc[i]
@@ -72,6 +84,7 @@ def main():
         d[1] += acc[i]
         d[2] += c[0]
         d[3] += c[1]
+    width = max(68, max(len(k) for k in by))
     lines = ["# forward only, batch %d, %dx%d, per-op HIP events averaged over %d passes" % (B, S, S, reps),
              "# roof = max(FLOPs / 2.5 PFLOP/s, layer-fused bytes / 8 TB/s) / time; a fused BasicBlock is one row (both convs)",
              "%-68s %3s %9s %9s %9s %8s %6s" % ("op", "n", "ms_total", "TFLOP/s", "GB/s", "us/op", "roof")]
