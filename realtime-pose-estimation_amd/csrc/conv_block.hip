@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(512) conv_block_pc_kernel(const BlockArgs a) {
       half8 o = ov + rv;                                   // fp16 add, round-to-nearest-even = the wrapper's add
       short8 b = __builtin_bit_cast(short8, o);
       b = b & ~(b >> 15);
-      *reinterpret_cast<short8*>(yb + yoffr[it]) = b;      // every tile is complete
+      store16_wt(yb + yoffr[it], b);                       // every tile is complete
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slab is read: the next request may overwrite it
   };

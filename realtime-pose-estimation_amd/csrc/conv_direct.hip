@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kDWaves * 64) conv1x1_direct_kernel(const Dire
           bsh = bsh & ~(bsh >> 15);
           v = __builtin_bit_cast(half8, bsh);
         }
-        *reinterpret_cast<half8*>(a.y + (size_t)p * a.out_ld + cblk + pslot[it] * 8) = v;
+        store16_wt(a.y + (size_t)p * a.out_ld + cblk + pslot[it] * 8, v);
       }
     }
 #pragma unroll

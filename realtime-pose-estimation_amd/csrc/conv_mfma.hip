@@ -371,7 +371,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         for (int j = 0; j < EPS; ++j) v[j] = v[j] > (T)0.f ? v[j] : (T)0.f;
       }
       __builtin_memcpy(&raw, v, 16);
-      *reinterpret_cast<uint4*>(yout + pix * a.out_ld + ch) = raw;
+      // (the four sub-pixel classes of a transposed conv write interleaved pieces of the same 128-byte lines, which
+      // must meet in L2: plain stores there - write-through made the deconv 222 -> 259 us)
+      if (a.o_mul == 1) store16_wt(yout + pix * a.out_ld + ch, raw);
+      else *reinterpret_cast<uint4*>(yout + pix * a.out_ld + ch) = raw;
     }
   }
 #ifdef RTPE_CONV_STAMPS

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kPWaves * 64) conv1x1_pair_kernel(const PairAr
       bsh = bsh & ~(bsh >> 15);                             // x > 0 ? x : +0 on the sign bits
       v = __builtin_bit_cast(half8, bsh);
       *reinterpret_cast<half8*>(slab + pix * kRowB + pslot * 16) = v;
-      if (p < a.P) *reinterpret_cast<half8*>(a.y + (size_t)p * a.y_ld + pslot * 8) = v;
+      if (p < a.P) store16_wt(a.y + (size_t)p * a.y_ld + pslot * 8, v);
     }
     // ---- GEMM 2: u[64][16 pixels] = W1' . y, y straight from the slab (lane (r, g): pixel r, channels 32 k + 8 g ..) ----
     float4v acc2[kM2];

@@ -613,7 +613,7 @@ conv_stream_kernel(const ConvArgs a) {
       for (int it = 0; it < NIT; ++it) {
         int e = epos[it];
         asm volatile("" : "+v"(e));
-        if ((e >> 16) < hy && ((e >> 8) & 255) < hx) *reinterpret_cast<half8*>(yb + piece_off(e, ld2)) = ov[it];
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx) store16_wt(yb + piece_off(e, ld2), ov[it]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS traffic on the buffer is over

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
     for (int j = 0; j < EPS; ++j) o[j] = (T)((acc[j] > 0.f || !a.relu) ? acc[j] : 0.f);
     uint4 oraw;
     __builtin_memcpy(&oraw, o, 16);
-    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.y) + (((size_t)n * a.H + y) * a.W + x) * a.out_ld + cs * EPS) = oraw;
+    store16_wt(reinterpret_cast<T*>(a.y) + (((size_t)n * a.H + y) * a.W + x) * a.out_ld + cs * EPS, oraw);
   }
 }
 
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
       }
       uint4v raw;
       __builtin_memcpy(&raw, o, 16);
-      *reinterpret_cast<uint4v*>(dst + q * EPS) = raw;
+      store16_wt(dst + q * EPS, raw);
     }
   }
 }
