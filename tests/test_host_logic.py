@@ -536,3 +536,19 @@ def test_autotune_cache_defaults_to_one_file_per_node_under_torchrun(monkeypatch
     assert ph._tuned_file() == ""
     monkeypatch.setenv("RTPE_AUTOTUNE_CACHE", "/somewhere/t.json")
     assert ph._tuned_file() == "/somewhere/t.json"
+
+
+def test_workspace_slot_is_per_thread():
+    """the workspace slot of the forwards issued next (several forwards in flight use one each) belongs to the calling
+    thread: a pipeline in another thread starts at slot 0 and does not see this thread's"""
+    import threading
+    from rtpe.third_party import pose_higher_hrnet as ph
+    assert ph.set_workspace_slot(2) == 0
+    try:
+        seen = []
+        t = threading.Thread(target=lambda: seen.append((ph._WS_SLOT[0], ph.set_workspace_slot(5))))
+        t.start()
+        t.join()
+        assert seen == [(0, 0)] and ph._WS_SLOT[0] == 2
+    finally:
+        assert ph.set_workspace_slot(0) == 2
