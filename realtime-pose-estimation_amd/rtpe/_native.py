@@ -128,6 +128,11 @@ def lib():
                 "rtpe: %s not found - the HIP extension is not built and there is no CPU "
                 "fallback.  Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
                 "from the repository root (needs hipcc)." % LIB_PATH)
+        # PyTorch brings its own copy of the HIP runtime (torch/lib/libamdhip64.so); this library is linked against the
+        # system's.  Whichever is in the process first serves both (same SONAME) - but only if torch's is loaded BEFORE this
+        # library: loaded after it, a second runtime instance comes up and one of the two finds "no ROCm-capable device"
+        # (seen with `g.build(); g.smoke()` in one process: build() loaded this library before anything imported torch).
+        import torch  # noqa: F401
         try:
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
