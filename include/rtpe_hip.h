@@ -19,8 +19,22 @@
  *     rtpe_hrnet_destroy().  No device allocation, no host sync inside
  *     rtpe_hrnet_forward() or any launch function unless documented
  *     ("host-returning").
- *   - all device work is enqueued on the given stream (stream-ordered,
- *     graph-capturable); handles are independent (one process per GPU).
+ *   - all device work is ordered behind what the given stream holds at the
+ *     call and in front of what is enqueued on it afterwards.  Forwards of a
+ *     program with parallel regions (rtpe_op_desc.lane / region) run the ops of
+ *     lanes 1..3 on INTERNAL non-blocking streams that fork from and join into
+ *     the given stream by events (option "lanes", default on); those streams
+ *     and events are created by the first such forward of a handle (the only
+ *     device-resource creation outside rtpe_hrnet_create) and destroyed with
+ *     it.  rtpe_hrnet_forward_flags(..., RTPE_FWD_NO_LANES) keeps every launch
+ *     on the given stream: use it under stream capture and with stream
+ *     priorities that the internal streams must not escape.
+ *   - threads: handles are independent (one process per GPU is the intended
+ *     shape).  Several host threads may call forwards on ONE handle at the
+ *     same time (each with its own stream and workspace): a forward that uses
+ *     the lanes holds a per-handle lock while it enqueues, so such calls
+ *     enqueue one after the other; create / destroy / autotune of a handle
+ *     must not overlap other calls on it.  rtpe_set_option is process-wide.
  *   - devices: functions that take an rtpe_hrnet handle make the handle's
  *     device current for the call and restore the caller's device before they
  *     return (rtpe_hrnet_create included); their buffers and stream must
@@ -51,6 +65,9 @@ extern "C" {
 #define RTPE_DTYPE_F32 2
 
 const char* rtpe_last_error_string(void);
+/* ABI revision: 2 = rtpe_op_desc carries lane / region (sizeof 112 -> 120),
+ * rtpe_hrnet_forward_flags exists.  A caller built against revision 1 must
+ * not pass its descriptors to this library: check before rtpe_hrnet_create. */
 int rtpe_version(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 int rtpe_device_count(void);
@@ -175,6 +192,17 @@ int rtpe_hrnet_forward(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                        int32_t N, int32_t H, int32_t W,
                        void* preds, void* refined, int32_t out_dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* rtpe_hrnet_forward with per-call switches (flags: RTPE_FWD_*; unknown bits
+ * are an error).  RTPE_FWD_NO_LANES: every op on `stream`, whatever the option
+ * "lanes" says (callers that overlap whole forwards on streams of their own,
+ * rtpe/engine.py TeacherPipeline.stream; graph capture). */
+#define RTPE_FWD_NO_LANES 1u
+int rtpe_hrnet_forward_flags(rtpe_hrnet* h, const void* x, int32_t x_dtype,
+                             int32_t N, int32_t H, int32_t W,
+                             void* preds, void* refined, int32_t out_dtype,
+                             void* workspace, size_t workspace_bytes, void* stream,
+                             uint32_t flags);
 
 /* Same, but brackets every op with HIP events on `stream` and returns the
  * per-op time in ms (op_ms[n_ops]).  Host-returning (synchronises). */

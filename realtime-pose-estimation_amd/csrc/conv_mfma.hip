@@ -649,8 +649,8 @@ static bool direct_tile(const ConvPlan& p, ConvTile* out) {
   return true;
 }
 
-ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
-  {
+ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct) {
+  if (allow_direct) {
     ConvTile t;
     if (direct_tile(p, &t)) return t;
   }

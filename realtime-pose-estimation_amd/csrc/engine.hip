@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <chrono>
+#include <mutex>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -61,6 +62,10 @@ struct rtpe_hrnet {
   int n_preds, n_refined;
   // parallel regions (rtpe_op_desc::lane / region): internal streams for lanes 1..3 and one event per op whose output
   // another lane reads, created on first use; wait_ops[i] = ops of other lanes whose output op i reads
+  // THREADS: the lane streams and events are state of the handle; a forward with lanes on holds lane_mu from the creation
+  // of that state (first such forward) to the join of its last region, so two host threads on one handle enqueue their
+  // lane regions one after the other (their kernels still overlap on the GPU when they use different streams)
+  std::mutex lane_mu;
   hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> op_event;
   std::vector<char> needs_event;
@@ -109,7 +114,7 @@ extern "C" int rtpe_get_option(const char* name, int32_t* value) {
 }
 
 extern "C" const char* rtpe_last_error_string(void) { return g_err.c_str(); }
-extern "C" int rtpe_version(void) { return 1; }
+extern "C" int rtpe_version(void) { return 2; }   // 2: rtpe_op_desc has lane / region, rtpe_hrnet_forward_flags
 extern "C" int rtpe_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -232,7 +237,7 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
         d2.ksize != 1 || d1.stride != 1 || d2.stride != 1 || d1.res_t < 0 || d2.res_t >= 0 || d2.in_t != d1.out_t ||
         d2.in_coff != d1.out_coff || d2.cin != d1.cout || !conv_pair_supports(d1.cin, d1.cout, d2.cout) ||
         h->tensors[d1.in_t].reserved == 4 || d1.reserved[2] > 0 || d2.reserved[2] > 0 || d2.out_t == d1.in_t ||
-        d2.out_t == d1.res_t || d2.out_t == d1.out_t)
+        d2.out_t == d1.res_t || d2.out_t == d1.out_t || d1.lane != d2.lane || d1.region != d2.region)
       continue;
     a1.pair = 1;
     h->ops[i + 1].pair = 2;
@@ -245,6 +250,7 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     h->needs_event.assign(n_ops, 0);
     h->wait_ops.assign(n_ops, std::vector<int>());
     std::vector<int> writer(h->tensors.size(), -1);
+    std::vector<std::vector<int>> readers(h->tensors.size());     // ops that read a tensor since its last writer
     for (int i = 0; i < n_ops; ++i) {
       const rtpe_op_desc& d = h->ops[i].d;
       if (d.lane < 0 || d.lane > 3 || d.region < 0) { set_error("op %d: lane %d region %d", i, d.lane, d.region); delete h; return RTPE_E_INVALID; }
@@ -262,6 +268,20 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
           h->wait_ops[i].push_back(j);
         }
       }
+      // write after read: a lane that overwrites a tensor (an in-place op, a shared slot written through `into=`) waits
+      // for the ops of OTHER lanes that read the previous contents
+      if (d.out_t >= 0) {
+        for (int j : readers[d.out_t]) {
+          if (j != i && h->ops[j].d.region == d.region && d.region > 0 && h->ops[j].d.lane != d.lane) {
+            h->needs_event[j] = 1;
+            h->wait_ops[i].push_back(j);
+          }
+        }
+        readers[d.out_t].clear();
+      }
+      if (d.kind != RTPE_OP_FUSE && d.in_t >= 0) readers[d.in_t].push_back(i);
+      if (d.res_t >= 0) readers[d.res_t].push_back(i);
+      for (int t = 0; t < d.n_terms; ++t) readers[d.term_t[t]].push_back(i);
       if (d.out_t >= 0) writer[d.out_t] = i;
     }
   }
@@ -426,7 +446,7 @@ static int read_op_times(const rtpe_hrnet* h, const Events& ev, bool fused_mode,
 static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, void* preds, void* refined,
                int out_dtype, void* ws, size_t ws_bytes, hipStream_t s_main, float* op_ms, int n_ms,
                int only_op = -1, int only_k = -1, const ConvTile* force = nullptr,
-               std::vector<hipEvent_t>* rec = nullptr, const void* aux = nullptr) {
+               std::vector<hipEvent_t>* rec = nullptr, const void* aux = nullptr, uint32_t fwd_flags = 0) {
   RTPE_REQUIRE(h && x && ws, "forward: null argument");
   static const int host_prof = env_int("RTPE_HOST_PROF", 0);       // host time of a forward: where it goes (stderr)
   typedef std::chrono::steady_clock hclock;
@@ -487,10 +507,12 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
   // caller's stream at the region's first op and joins it behind its last; an op waits for the events of the ops of
   // other lanes whose output it reads.  Timed / recorded / single-op runs stay on one stream (one op after another).
   bool lanes_on = false;
-  if (h->has_regions && !timed && rec == nullptr && only_op < 0 && force == nullptr) {
+  if (h->has_regions && !timed && rec == nullptr && only_op < 0 && force == nullptr && !(fwd_flags & RTPE_FWD_NO_LANES)) {
     const int opt = get_option(kOptLanes);
     lanes_on = opt == 1 || (opt == 2 && (long long)N * H * W <= 4ll * 640 * 640);
   }
+  std::unique_lock<std::mutex> lane_lock;
+  if (lanes_on) lane_lock = std::unique_lock<std::mutex>(h->lane_mu);   // held until the last region has joined (return)
   if (lanes_on && h->fork_event == nullptr) {
     for (int l = 1; l < 4; ++l) RTPE_HIP_CHECK(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
     h->op_event.assign(h->ops.size() + 4, nullptr);
@@ -503,6 +525,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
   const bool pairs_on = get_option(kOptPair1x1) != 0 && only_op < 0 && force == nullptr;
   ConvArgs pair_args;
   memset(&pair_args, 0, sizeof(pair_args));
+  bool pair_pending = false;                              // the head of a 1x1 pair waits for its tail's launch
   int cur_region = 0;
   bool lane_used[4] = {false, false, false, false};
   auto join_lanes = [&]() -> hipError_t {
@@ -644,6 +667,11 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           tile = (*tuned)[i * 4 + k];
         else
           tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos);
+        // the direct 1x1 kernel and the 1x1 pair address their input through one 2-GiB buffer window and write plain
+        // NHWC rows: a larger view (batch >= 164 at 640 x 640 for the 256 -> 64 conv) or another output form takes the
+        // one-workgroup-per-tile kernel, whose staging falls back per image
+        const bool direct_ok = a.x_bytes < 0x80000000ull && a.y != nullptr && a.y_nchw == nullptr && a.o_mul == 1;
+        if (tile.kind == 4 && !direct_ok) tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos, /*allow_direct=*/false);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
         if (merge) {
           // class k's weights and offsets go into the argument block of class 0; the launch follows the last class
@@ -654,11 +682,13 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           if (k == o.n_geom - 1) RTPE_HP_LAUNCH(rc = conv_launch(o.plan[0], merged_tile, merged, s));
           continue;
         }
-        if (pairs_on && o.pair == 1) {                    // launched together with the next op (conv_pair.hip)
+        if (pairs_on && o.pair == 1 && direct_ok) {       // launched together with the next op (conv_pair.hip)
           pair_args = a;
+          pair_pending = true;
           continue;
         }
-        if (pairs_on && o.pair == 2) {
+        if (pair_pending) {
+          pair_pending = false;
           RTPE_HP_LAUNCH(rc = conv_pair_launch(h->ops[i - 1].plan[0], pair_args, o.plan[0], a, s));
           continue;
         }
@@ -735,7 +765,11 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       RTPE_HP_LAUNCH(rc = fuse_launch(a, s));
     }
     if (rc != RTPE_OK) return rc;
-    if (lanes_on && cur_region > 0 && h->needs_event[i]) RTPE_HIP_CHECK(hipEventRecord(h->op_event[i], s));
+    if (lanes_on && cur_region > 0) {
+      // (a 1x1 pair is ONE kernel, launched at the tail's place: the head's output exists behind that launch)
+      if (h->needs_event[i] && !pair_pending) RTPE_HIP_CHECK(hipEventRecord(h->op_event[i], s));
+      if (pairs_on && o.pair == 2 && h->needs_event[i - 1]) RTPE_HIP_CHECK(hipEventRecord(h->op_event[i - 1], s));
+    }
     const bool has_event = op_has_event(h, i, force == nullptr && only_op < 0);
     if (timed && has_event) RTPE_HIP_CHECK(hipEventRecord(ev[i + 1], s));
     if (rec && has_event) RTPE_HIP_CHECK(hipEventRecord((*rec)[i + 1], s));
@@ -766,6 +800,14 @@ extern "C" int rtpe_hrnet_forward(rtpe_hrnet* h, const void* x, int32_t x_dtype,
                                   size_t workspace_bytes, void* stream) {
   return run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes,
              reinterpret_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+extern "C" int rtpe_hrnet_forward_flags(rtpe_hrnet* h, const void* x, int32_t x_dtype, int32_t N, int32_t H,
+                                        int32_t W, void* preds, void* refined, int32_t out_dtype, void* workspace,
+                                        size_t workspace_bytes, void* stream, uint32_t flags) {
+  RTPE_REQUIRE((flags & ~(uint32_t)RTPE_FWD_NO_LANES) == 0, "forward_flags: unknown flag bits 0x%x", flags);
+  return run(h, x, x_dtype, N, H, W, preds, refined, out_dtype, workspace, workspace_bytes,
+             reinterpret_cast<hipStream_t>(stream), nullptr, 0, -1, -1, nullptr, nullptr, nullptr, flags);
 }
 
 extern "C" int rtpe_hrnet_forward_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const void* aux_nchw_f32, int32_t N,

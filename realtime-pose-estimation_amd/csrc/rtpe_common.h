@@ -193,7 +193,8 @@ struct ConvGeom {       // logical layer, independent of the batch
 
 ConvPlan conv_make_plan(const ConvGeom& g);
 // choose the tile for a position grid (N images of H_pos x W_pos positions)
-ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos);
+// (allow_direct = false: never the direct 1x1 kernel, whose launch needs a < 2 GiB input view and a plain NHWC output)
+ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct = true);
 // LDS bytes per row of the staged input tile of a tw-wide output tile: halo_w * pstride, padded (fp16) so that a
 // 16-pixel MFMA column tile which wraps to the next output row keeps the bank pattern of consecutive pixels
 int conv_row_pitch(const ConvPlan& p, int tw);

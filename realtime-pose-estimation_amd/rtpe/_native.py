@@ -7,7 +7,7 @@ instructions (``python -c "import __graft_entry__ as g; g.build()"``).
 import ctypes
 import os
 from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64,
-                    c_size_t, c_void_p)
+                    c_size_t, c_uint32, c_void_p)
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # RTPE_LIBRARY: another build of the same ABI (A/B measurements of two builds on one GPU box)
@@ -46,6 +46,8 @@ _SIGS = {
     "rtpe_hrnet_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "rtpe_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "rtpe_hrnet_forward_flags": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                           c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p, c_uint32]),
     "rtpe_hrnet_forward_aux": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "rtpe_rgb_to_alt": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

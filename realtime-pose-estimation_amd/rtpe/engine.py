@@ -152,8 +152,8 @@ class TeacherPipeline:
         alternate between that many internal HIP streams, each with an activation workspace of its own, so that the
         low-occupancy layers of one batch (stem, layer1, transitions, heads: HBM- and latency-bound) run beside the
         matrix-bound stages of the other - 14.5 -> 13.0-13.4 ms per forward at batch 32, 3.30 -> 2.13 ms at batch 1
-        (`tools/two_stream_probe.py`).  Inside this loop the executor's parallel lanes are switched off (both at once are
-        slower than either).  1 = every forward on the caller's stream.  ``exclusive(k)`` true: the forward of batch k
+        (`tools/two_stream_probe.py`).  The forwards of this loop run without the executor's parallel lanes (both at once
+        are slower than either): a per-call flag, the process-wide option is not touched.  1 = every forward on the caller's stream.  ``exclusive(k)`` true: the forward of batch k
         runs alone - it starts when the forwards in flight are done and the next one starts behind it (bench.py times the
         kernels of such a step with per-op events: a kernel's duration beside another forward is not its own).
 
@@ -170,18 +170,11 @@ class TeacherPipeline:
         if n_fwd < 1 or n_fwd > 4:
             raise ValueError("in_flight must be 1..4, not %r" % (n_fwd,))
         fwd_streams = None
-        lanes_before = None
         if n_fwd > 1:
             fwd_streams = self.__dict__.get("_forward_streams")
             if fwd_streams is None or len(fwd_streams) < n_fwd:
                 fwd_streams = self._forward_streams = [torch.cuda.Stream(self.device) for _ in range(n_fwd)]
-            from . import _native as nat
-            from .third_party.pose_higher_hrnet import set_workspace_slot
-            import ctypes
-            v = ctypes.c_int32()
-            nat.check(nat.lib().rtpe_get_option(b"lanes", ctypes.byref(v)))
-            lanes_before = v.value
-            nat.check(nat.lib().rtpe_set_option(b"lanes", 0))
+            from .third_party.pose_higher_hrnet import FWD_NO_LANES, set_forward_flags, set_workspace_slot
         side = None
         if mode == "side":
             side = self.__dict__.get("_decode_stream")
@@ -224,11 +217,15 @@ class TeacherPipeline:
                                     fs.wait_stream(other)
                         after_alone = fs if alone else None
                         x.record_stream(fs)
+                        # lanes off for THIS call only (a per-call flag of the ABI: nothing process-wide is touched,
+                        # and nothing stays changed while the generator is suspended or if it is abandoned)
                         prev_slot = set_workspace_slot(1 + k % n_fwd)
+                        prev_flags = set_forward_flags(FWD_NO_LANES)
                         try:
                             with torch.cuda.stream(fs):
                                 preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
                         finally:
+                            set_forward_flags(prev_flags)
                             set_workspace_slot(prev_slot)
                     else:
                         preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
@@ -262,16 +259,24 @@ class TeacherPipeline:
             if fwd_streams is not None:
                 for fs in fwd_streams[:n_fwd]:
                     main.wait_stream(fs)
-                nat.check(nat.lib().rtpe_set_option(b"lanes", lanes_before))
 
-    def gather(self, image_ids, results, equal_counts=False):
+    def gather(self, image_ids, results, equal_counts=False, force_collective=False):
         """all-gather of the decoded keypoints over the process group (RCCL).  ``equal_counts``:
-        every rank contributes the same number of images (no count exchange, no host sync)."""
-        import torch.distributed as dist
+        every rank contributes the same number of images (no count exchange, no host sync).
+        ``force_collective``: issue the collective also in a process group of ONE rank (a world of one is
+        otherwise answered locally; the switch lets a single GPU exercise the RCCL calls)."""
         rec = pack_records(image_ids, results, self.device)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not _collectives_on(force_collective):
             return rec
         return all_gather_records(rec, equal_counts)
+
+
+def _collectives_on(force_collective=False):
+    """a process group is up and has more than one rank - or one rank and the caller insists"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(force_collective)
 
 
 def _collective_tensor(t):
@@ -393,16 +398,17 @@ def image_id_of(name):
     return int(stem)
 
 
-def run_sharded_list(names, infer, batch_size, device):
+def run_sharded_list(names, infer, batch_size, device, force_collective=False):
     """configs[3]: one image list, one process per GPU.  ``names`` is the WHOLE list, identical on every rank;
     this rank takes its contiguous block (``shard_indices``: 100 names over 8 ranks -> 13,13,13,13,12,12,12,12),
     runs it in batches of ``batch_size`` (the last batch of a shard is short, the shards are uneven) through
     ``infer(list_of_names) -> [(people, scores)] per name``, and the decoded keypoints of ALL ranks are
     all-gathered as fixed-size records, with a count exchange because the shards differ in length.  No other
     collective touches the data path.  Returns ``{image_id: (kpts (P,17,4), scores (P))}`` for the whole list
-    on every rank, after checking that every image of the list came back exactly once."""
+    on every rank, after checking that every image of the list came back exactly once.  ``force_collective``: run
+    the count exchange and the gather also when the process group has a single rank."""
     import torch.distributed as dist
-    on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    on = _collectives_on(force_collective)
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     mine = shard_indices(len(names), rank, world)
     ids = [image_id_of(names[i]) for i in range(len(names))]
@@ -427,11 +433,12 @@ def run_sharded_list(names, infer, batch_size, device):
     return out
 
 
-def broadcast_state_dict(sd, src=0, device=None):
+def broadcast_state_dict(sd, src=0, device=None, force_collective=False):
     """rank ``src`` holds the checkpoint; every rank gets the tensors over
-    RCCL as ONE packed buffer per dtype."""
+    RCCL as ONE packed buffer per dtype.  ``force_collective``: broadcast also in a
+    process group of one rank."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on(force_collective):
         return sd
     keys = sorted(sd.keys())
     out = {}

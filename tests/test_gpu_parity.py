@@ -955,6 +955,70 @@ def test_run_sharded_list_on_one_rank(nat, teacher):
     assert n_people > 0
 
 
+def test_rccl_collectives_on_device_tensors_one_rank(nat, teacher):
+    """SURVEY section 8e on hardware: a process group on the ``nccl`` backend (= RCCL) with the one rank a test box
+    has, created in THIS process; ``force_collective`` makes the world of one take the collective branch, so
+    ``dist.broadcast`` / ``all_gather`` / ``all_gather_into_tensor`` run on DEVICE tensors through RCCL:
+    ``broadcast_state_dict`` (one packed buffer per dtype), both forms of ``all_gather_records`` and
+    ``run_sharded_list`` (count exchange + padded gather) - results equal to the local answers."""
+    import socket
+    import torch.distributed as dist
+    from rtpe import engine
+    assert not dist.is_initialized()
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl"
+        m, sd = teacher("W0")
+        # (1) weights: fp32 + fp16 + int64 entries, one packed device buffer per dtype through dist.broadcast
+        part = {k: v for i, (k, v) in enumerate(sorted(sd.items())) if i < 40}
+        part["half.w"] = torch.randn(7, 5).half()
+        part["bn.num_batches_tracked"] = torch.tensor(3, dtype=torch.int64)
+        got = engine.broadcast_state_dict(part, src=0, device="cuda:0", force_collective=True)
+        assert got is not part and sorted(got) == sorted(part)
+        for k in part:
+            assert got[k].dtype == part[k].dtype and got[k].shape == part[k].shape
+            assert torch.equal(got[k], part[k]), k
+        # (2) records of a real forward + decode, gathered in both forms on the device
+        pipe = engine.TeacherPipeline(m, device="cuda:0")
+        x = synth.make_images(3, 128, 128, seed=5).to("cuda:0")
+        res = pipe(x)
+        local = engine.pack_records([11, 12, 13], res, pipe.device)
+        for eq in (True, False):
+            rec = pipe.gather([11, 12, 13], res, equal_counts=eq, force_collective=True)
+            assert rec.is_cuda and rec.shape == local.shape
+            assert torch.equal(rec, local)
+        # (3) configs[3]'s entry point through the collective branch
+        names = ["%012d.jpg" % i for i in (7, 9, 21, 40, 41)]
+        gen = torch.Generator(device="cuda:0")
+        kept = {}
+
+        def infer(names_part):
+            xb = torch.empty((len(names_part), 3, 128, 128), device="cuda:0")
+            for i, nm in enumerate(names_part):
+                gen.manual_seed(engine.image_id_of(nm))
+                xb[i] = torch.randn(3, 128, 128, generator=gen, device="cuda:0")
+            r = pipe(xb)
+            for nm, one in zip(names_part, r):
+                kept[engine.image_id_of(nm)] = one
+            return r
+        out = engine.run_sharded_list(names, infer, 2, torch.device("cuda:0"), force_collective=True)
+        assert sorted(out) == [7, 9, 21, 40, 41]
+        for img_id, (kp, sc) in out.items():
+            people, scores = kept[img_id]
+            n = min(len(people) if people.ndim == 3 else 0, engine.MAX_PEOPLE_RECORD)
+            assert kp.shape == (n, 17, 4)
+            if n:
+                np.testing.assert_array_equal(kp, people[:n, :, :4])
+                np.testing.assert_array_equal(sc, np.array(scores[:n], np.float32))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_end_to_end_pipeline_and_margin_aware_indices(nat, teacher):
     """forward + decode on the GPU vs oracle forward + oracle decode.  Random-weight
     heat maps are noise, so candidates are compared where the CPU and GPU maps
@@ -1700,6 +1764,88 @@ def test_parallel_lanes_do_not_change_the_network_output(nat, teacher, w48_shape
                 assert torch.equal(p0, p1) and torch.equal(r0, r1), (n, hw, rep)
     finally:
         nat.check(L.rtpe_set_option(b"lanes", 1))
+
+
+def test_two_threads_forward_on_one_handle_with_lanes(nat, teacher):
+    """the lane streams and events belong to the handle: two host threads that forward on ONE model at the same time
+    (each on a stream and a workspace slot of its own, lanes on) must both get the bits of the single-threaded run -
+    the executor serialises the enqueue of lane regions per handle (include/rtpe_hip.h, "threads")"""
+    import threading
+    from rtpe.third_party.pose_higher_hrnet import set_workspace_slot
+    L = nat.lib()
+    m, sd = teacher("W1")
+    nat.check(L.rtpe_set_option(b"lanes", 1))
+    xs = [synth.make_images(2, 96, 128, seed=60 + i).to("cuda:0") for i in range(2)]
+    with torch.no_grad():
+        want = [[t.clone() for t in m(x)] for x in xs]
+    torch.cuda.synchronize()
+    errors, got = [], [[], []]
+    start = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream("cuda:0")
+            set_workspace_slot(1 + i)
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(st):
+                for rep in range(12):
+                    p, r = m(xs[i])
+                    got[i].append((p, r))
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        assert len(got[i]) == 12
+        for p, r in got[i]:
+            assert torch.equal(p, want[i][0]) and torch.equal(r, want[i][1]), i
+
+
+def test_forward_flag_no_lanes_is_per_call(nat, teacher):
+    """TeacherPipeline.stream runs its forwards without the lanes through a per-call flag of the ABI
+    (rtpe_hrnet_forward_flags / RTPE_FWD_NO_LANES): the process-wide option stays what it was while a stream loop is
+    open, when it is abandoned half way, and with two loops interleaved; results equal the plain calls"""
+    import ctypes
+    from rtpe import engine
+    from rtpe.third_party import pose_higher_hrnet as ph
+    L = nat.lib()
+    m, sd = teacher("W0")
+
+    def lanes():
+        v = ctypes.c_int32()
+        nat.check(L.rtpe_get_option(b"lanes", ctypes.byref(v)))
+        return v.value
+    before = lanes()
+    pipe_a, pipe_b = engine.TeacherPipeline(m, device="cuda:0"), engine.TeacherPipeline(m, device="cuda:0")
+    xs = [synth.make_images(2, 64, 96, seed=80 + i).to("cuda:0") for i in range(4)]
+    want = [pipe_a(x) for x in xs]
+    ga, gb = pipe_a.stream(iter(xs)), pipe_b.stream(iter(xs))
+    ra = [next(ga)]
+    assert lanes() == before and ph._WS_SLOT.fwd_flags == 0
+    rb = [next(gb), next(gb)]
+    ra += list(ga)
+    assert lanes() == before
+    del gb                                                   # abandoned half way
+    assert lanes() == before and ph._WS_SLOT.fwd_flags == 0
+    for got, ref in zip(ra + rb, want + want[:2]):
+        for (gp, gs), (wp, ws_) in zip(got, ref):
+            np.testing.assert_array_equal(gp, wp)
+            np.testing.assert_array_equal(np.array(gs, np.float32), np.array(ws_, np.float32))
+    x = xs[0]
+    with torch.no_grad():
+        p0, r0 = m(x)
+        prev = ph.set_forward_flags(ph.FWD_NO_LANES)
+        try:
+            p1, r1 = m(x)
+        finally:
+            ph.set_forward_flags(prev)
+    assert torch.equal(p0, p1) and torch.equal(r0, r1)
 
 
 def test_eval_student_with_the_dual_head_student(nat, golden_dir):

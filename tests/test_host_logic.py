@@ -225,6 +225,43 @@ def test_two_rank_gather_and_weight_broadcast_gloo():
         assert a == [[0., 1., 2.], [3., 4., 5.]] and b == [3.] * 4 and n == 5
 
 
+def _one_rank_worker(port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    from rtpe import engine
+    calls = []
+    real_bc, real_ag, real_agt = dist.broadcast, dist.all_gather, dist.all_gather_into_tensor
+    dist.broadcast = lambda *a, **k: (calls.append("broadcast"), real_bc(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), real_ag(*a, **k))[1]
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append("all_gather_into_tensor"), real_agt(*a, **k))[1]
+    sd = {"a": torch.arange(6.).reshape(2, 3), "b": torch.ones(4).half(), "n": torch.tensor(5)}
+    assert engine.broadcast_state_dict(sd, 0, "cpu") is sd and not calls          # a world of one answers locally
+    out = engine.broadcast_state_dict(sd, 0, "cpu", force_collective=True)
+    assert calls == ["broadcast"] * 3 and all(torch.equal(out[k], sd[k]) for k in sd)
+    del calls[:]
+    names = ["%012d.jpg" % i for i in (3, 5, 8)]
+    infer = lambda part: [(np.full((1, 17, 4), float(engine.image_id_of(n)), np.float32), [0.5]) for n in part]
+    assert sorted(engine.run_sharded_list(names, infer, 2, "cpu")) == [3, 5, 8] and not calls
+    got = engine.run_sharded_list(names, infer, 2, "cpu", force_collective=True)
+    assert calls == ["all_gather", "all_gather_into_tensor"]
+    assert sorted(got) == [3, 5, 8] and all(float(got[i][0][0, 0, 0]) == float(i) for i in got)
+    q.put("ok")
+    dist.destroy_process_group()
+
+
+def test_force_collective_takes_the_collective_branch_with_one_rank():
+    """the switch behind the one-GPU RCCL test (tests/test_gpu_parity.py): with it a process group of ONE rank
+    issues the same collectives as a larger one; without it the world of one is answered locally"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(31500 + os.getpid() % 2000, q))
+    p.start()
+    assert q.get(timeout=120) == "ok"
+    p.join(60)
+    assert p.exitcode == 0
+
+
 def test_student_state_dict_and_program(built, golden_dir):
     """config 5: AttentionStudent keeps the reference's parameter names/shapes (students.py:595-722,
     incl. the per-submodule ``load_state_dicts`` files) and compiles to one program"""

@@ -285,6 +285,12 @@ def gen_selfspread(ref):
             case("%s_img%d" % (variant, i), model, xb[i:i + 1], 4 if i == 0 else 8)
         for name, t in imgs.items():
             case("%s_%s" % (variant, name), model, t, 8)
+    # W1 (BatchNorm statistics away from identity; maps of +-4.2, beyond the teacher's span): the 128x192 case of
+    # hrnet_small.npz and the 640x640 case of hrnet_640.npz (stride 8), so that those two tests are bounded by the
+    # reference itself as well
+    model = ref.teacher(ref.weights("W1"))
+    case("W1_small", model, xs, 0)
+    case("W1_640", model, synth.make_images(1, 640, 640), 8)
 
 
 def gen_decode_branches(ref):
