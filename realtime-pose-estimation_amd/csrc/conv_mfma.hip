@@ -555,42 +555,29 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   return true;
 }
 
-// second-generation streaming kernel (conv_stream.hip, kind 3): 4 MFMA waves x nt 16-pixel tiles cover the
-// th x tw tile (surplus tiles allowed: 20 x 20 = 25 tiles on 4 x 7), two halo buffers, tiles staged through the
-// loader waves' registers
-struct Tile2Cand { int nt, th, tw; };
-static const Tile2Cand kCands2[] = {
-    {5, 16, 20}, {5, 20, 16}, {5, 8, 40}, {5, 10, 32}, {4, 16, 16}, {4, 8, 32}, {7, 20, 20}, {7, 28, 16}, {7, 16, 28}, {7, 14, 32},
-    {2, 8, 16},
-};
-
-static bool stream2_tile(const ConvPlan& p, const Tile2Cand& c, int N, int H_pos, int W_pos, bool want_resident, ConvTile* out) {
-  if (!conv_stream_supports(p)) return false;
-  if (p.in_mul == 1 ? c.nt == 2 : (c.nt != 2 || p.n_cchunks != 1)) return false;   // stride 2: 2 tiles per wave, Cin = 48
-  const int waves = 4;
-  if (c.th * c.tw > 16 * c.nt * waves || c.th * c.tw <= 16 * c.nt * (waves - 1)) return false;
-  const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
-  if (hw * 6 > 256) return false;
-  const bool resident = want_resident && p.n_cchunks <= 2;
-  if (want_resident != resident) return false;
-  if (!conv_stream2_tile_fits(hh, hw, resident) || !conv_stream2_drain_fits(p.mt, c.nt, hh, hw, resident)) return false;
-  const size_t in_tile = (size_t)hh * conv_row_pitch(p, c.tw);
-  const size_t out_tile = (size_t)waves * c.nt * 16 * (p.mt * 32 + 16);
-  size_t buf = in_tile > out_tile ? in_tile : out_tile;
+// producer / consumer streaming kernel (conv_stream_pc.hip, kind 3): the launch shapes of the streaming kernel with 4
+// pixel-tile waves (x 2 groups), two halo buffers and NO output slab: a buffer holds the halo tile only
+static bool stream_pc_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, bool want_resident, ConvTile* out) {
+  if (!conv_stream_pc_supports(p) || c.waves != 4 || (c.nt != 4 && c.nt != 5)) return false;
+  const int hh = c.th + 2, hw = c.tw + 2;
+  if (hw * 6 > 256 || c.th > 255 || c.tw > 255) return false;
+  size_t buf = (size_t)hh * conv_row_pitch(p, c.tw);
   buf = (buf + 255) / 256 * 256;
+  const bool resident = want_resident && p.n_cchunks <= 2 && conv_stream_pc_lds(p, (int)buf, 2 * p.n_cchunks) <= 160 * 1024;
+  if (want_resident != resident) return false;
   const int nw = resident ? 2 * p.n_cchunks : 3;
-  if (conv_stream2_lds(p, (int)buf, nw) > 160 * 1024) return false;
+  if (conv_stream_pc_lds(p, (int)buf, nw) > 160 * 1024) return false;
   const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
   const long units = tiles * p.n_cb;
-  long G = 32;
+  long G = 32;                                            // one workgroup per CU
   const long need = (units + 7) / 8;
   if (G > need) G = need;
   G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
   memset(out, 0, sizeof(*out));
-  out->nt = c.nt; out->waves = waves; out->th = c.th; out->tw = c.tw;
+  out->nt = c.nt; out->waves = 4; out->th = c.th; out->tw = c.tw;
   out->kind = 3; out->grid = (int)(8 * G); out->buf_bytes = (int)buf; out->n_bufs = 2;
   out->n_wslots = nw;
-  out->lds_bytes = conv_stream2_lds(p, (int)buf, nw);
+  out->lds_bytes = conv_stream_pc_lds(p, (int)buf, nw);
   return true;
 }
 
@@ -620,20 +607,21 @@ static ConvTile make_stream_tile(const ConvPlan& p, int N, int H_pos, int W_pos)
   return best;
 }
 
-static ConvTile make_stream2_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
+static ConvTile make_stream_pc_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   double best_score = 1e30;
   ConvTile best;
   memset(&best, 0, sizeof(best));
-  for (const Tile2Cand& c : kCands2) {
+  for (const TileCand& c : kCands) {
     for (int res = 1; res >= 0; --res) {
       ConvTile t;
-      if (!stream2_tile(p, c, N, H_pos, W_pos, res != 0, &t)) continue;
+      if (!stream_pc_tile(p, c, N, H_pos, W_pos, res != 0, &t)) continue;
       const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
-                           ((double)H_pos * W_pos) * (16.0 * c.nt * 4 / (c.th * c.tw));
+                           ((double)H_pos * W_pos);
       const long units = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N * p.n_cb;
       const double rounds = (double)units / t.grid;
       const double imbalance = rounds >= 1.0 ? (double)((long)(rounds + 0.999)) / rounds : 1.0;
-      const double score = waste * imbalance * (res ? 0.8 : 1.0);
+      const double halo = (double)(c.th + 2) * (c.tw + 2) / ((double)c.th * c.tw);
+      const double score = waste * imbalance * (1.0 + 0.15 * (halo - 1.0)) * (res ? 0.8 : 1.0);
       if (score < best_score) { best_score = score; best = t; }
     }
   }
@@ -654,8 +642,8 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool all
     ConvTile t;
     if (direct_tile(p, &t)) return t;
   }
-  if (get_option(kOptStreamV2) == 2 && conv_stream_supports(p)) {
-    ConvTile t = make_stream2_tile(p, N, H_pos, W_pos);
+  if (get_option(kOptStreamPC) == 2 && conv_stream_pc_supports(p)) {
+    ConvTile t = make_stream_pc_tile(p, N, H_pos, W_pos);
     if (t.nt) return t;
   }
   static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
@@ -729,6 +717,10 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
+  if (t.kind == 3) {
+    static const int pcf = RTPE_DIAG_ENV_INT("RTPE_PC_FLAGS", 0);
+    a->pc_flags = pcf;
+  }
   static const int abl = RTPE_DIAG_ENV_INT("RTPE_STREAM_ABL", 0);
   a->ablate = abl;
   // ablations for profiling only (-DRTPE_DIAG builds): RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
@@ -778,7 +770,7 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     t.lds_bytes = tile_lds(p, c.th, c.tw, c.waves, c.nt);
     if (t.lds_bytes <= 160 * 1024) out->push_back(t);              // one workgroup per tile
     static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
-    if ((stream & 1) && get_option(kOptStreamV2) != 2) {
+    if ((stream & 1) && get_option(kOptStreamPC) != 2) {
       ConvTile st;
       if (stream_tile(p, c, N, H_pos, W_pos, &st)) out->push_back(st);   // streaming, LDS-DMA operands
       // two-chunk layers: resident weights leave room for 2 halo buffers, the weight ring for 3
@@ -786,26 +778,20 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
           st.n_bufs == 3)
         out->push_back(st);
     }
+    if ((stream & 1) && get_option(kOptStreamPC) != 0) {           // producer / consumer wave groups (conv_stream_pc.hip)
+      ConvTile st;
+      for (int res = 1; res >= 0; --res)
+        if (stream_pc_tile(p, c, N, H_pos, W_pos, res != 0, &st)) out->push_back(st);
+    }
   }
   {
     ConvTile dt;
     if (direct_tile(p, &dt)) out->push_back(dt);                 // 1x1: no staged tile at all (conv_direct.hip)
   }
-  // streaming v2 (option "stream_v2", default off): its own tile list
-  if (get_option(kOptStreamV2) != 0) {
-    for (const Tile2Cand& c : kCands2) {
-      const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
-                           ((double)H_pos * W_pos);
-      if (waste > 1.35 * min_waste && waste > 1.35) continue;
-      ConvTile st;
-      for (int res = 1; res >= 0; --res)
-        if (stream2_tile(p, c, N, H_pos, W_pos, res != 0, &st)) out->push_back(st);
-    }
-  }
 }
 
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
-  RTPE_REQUIRE(t.kind == 3 ? t.th * t.tw <= 16 * t.nt * t.waves : t.th * t.tw == 16 * t.nt * t.waves,
+  RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves,
                "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
   // a launch shape belongs to one plan (halo = taps x dilation, pixel stride): never run a foreign one
@@ -821,7 +807,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 2) return conv_stream_launch(p, t, a, s);
-  if (t.kind == 3) return conv_stream2_launch(p, t, a, s);
+  if (t.kind == 3) return conv_stream_pc_launch(p, t, a, s);
   if (t.kind == 4) return conv_direct_launch(p, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
                "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");

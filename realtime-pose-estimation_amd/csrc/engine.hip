@@ -78,9 +78,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_v2", "direct_1x1", "lanes", "tile_dma", "pair_1x1", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_V2", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", ""};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 0};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", ""};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", ""};
+static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -923,14 +923,13 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
             hd[2] / hd[5], hd[3] / hd[5], hd[12] / units, hd[13] / units, hd[4] / units, hd[14] / units, hd[10] / units, hd[6] / hd[11],
             hd[7] / hd[11], hd[8] / hd[11], hd[9] / hd[11]);
   }
-  else if (tile.kind == 3 && hd[4]) {
-    const unsigned long long nw = (unsigned long long)tile.grid * 4, stages = hd[4], units = hd[14] ? hd[14] : 1;
-    const unsigned long long nl = (unsigned long long)tile.grid * (tile.n_wslots == 3 ? 3 : 4), lstages = stages / 4 * (tile.n_wslots == 3 ? 3 : 4);
-    fprintf(stderr, "stream2 conv %dx%d nt%d grid %d wslots %d | per MFMA wave: total %llu cycles, %llu units | per stage: waitM %llu half0 %llu waitH %llu half1 %llu | "
-            "per unit: waitE %llu bn->slab %llu waitS %llu | tile loaders per stage: waitM %llu drain(+H) %llu rendezvous %llu wait-tile %llu write %llu load-issue %llu\n",
-            tile.th, tile.tw, tile.nt, tile.grid, tile.n_wslots, hd[15] / nw, units / nw, hd[0] / stages, hd[1] / stages, hd[2] / stages, hd[3] / stages,
-            hd[5] / units, hd[6] / units, hd[7] / units, hd[8] / lstages, hd[9] / lstages, hd[10] / lstages, hd[11] / lstages, hd[12] / lstages, hd[13] / lstages);
-    (void)nl;
+  else if (tile.kind == 3 && hd[5]) {
+    // conv_stream_pc.hip: slots 0-3 / 5 = multiplying group per stage, 6-9 / 11 = finishing group per stage
+    const unsigned long long nw = (unsigned long long)tile.grid * 8, ks = hd[5], es = hd[11] ? hd[11] : 1;
+    fprintf(stderr, "stream pc conv %dx%d nt%d grid %d wslots %d flags %d | per wave: total %llu cycles (prologue %llu, last epilogue %llu) | multiplying group per stage: waitM %llu half0 %llu "
+            "waitH %llu half1 %llu | finishing group per stage: waitM %llu requests %llu epilogue %llu (H, requests, final wait) %llu\n",
+            tile.th, tile.tw, tile.nt, tile.grid, tile.n_wslots, a.pc_flags, hd[15] / nw, hd[12] / nw, hd[13] / nw, hd[0] / ks, hd[1] / ks, hd[2] / ks, hd[3] / ks,
+            hd[6] / es, hd[7] / es, hd[8] / es, hd[9] / es);
   }
   else if (hd[5])
     fprintf(stderr, "conv stamps (kind %d): n %llu | per wave(-unit) cycles: setup %llu stage/wait1 %llu kloop %llu epilogue %llu total/wait2 %llu\n",
@@ -1102,7 +1101,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
   }
   out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
   out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
-                                                            : (int32_t)t.lds_bytes;   // v2: "/8" weight ring, "/9" resident weights
+                                                            : (int32_t)t.lds_bytes;   // pc: "/8" weight ring, "/9" resident weights
   return RTPE_OK;
 }
 

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamV2 = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kNumOptions = 8 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -159,6 +159,9 @@ struct ConvArgs {
   int buf_bytes;         // streaming kernel: bytes of one LDS tile buffer
   int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
   int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
+  int pc_flags;          // streaming pc kernel: 1 = the finishing group runs at a higher wave priority, 2 = the tile of the next
+                         // stage is requested in two halves around the mid-stage barrier (weight ring only), 4 = plain instead of
+                         // write-through row stores
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
   unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
@@ -177,7 +180,7 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int th, tw;
   size_t lds_bytes;
   int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
-                        // (conv_stream.hip), 3: streaming v2 (tiles through loader registers, loaders store), 4: direct 1x1 (conv_direct.hip)
+                        // (conv_stream.hip), 3: streaming, producer / consumer wave groups (conv_stream_pc.hip), 4: direct 1x1 (conv_direct.hip)
   int grid;             // streaming: number of workgroups
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
@@ -207,12 +210,11 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
 bool conv_stream_supports(const ConvPlan& p);
 size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots);
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
-// second-generation streaming kernel (ConvTile::kind == 3): tiles through the loader waves' registers, the loaders
-// also run the residual / ReLU / store phase; 4 MFMA + 4 loader waves, two halo buffers
-size_t conv_stream2_lds(const ConvPlan& p, int buf_bytes, int n_wslots);
-bool conv_stream2_tile_fits(int halo_h, int halo_w, bool resident);
-bool conv_stream2_drain_fits(int mt, int nt, int halo_h, int halo_w, bool resident);
-int conv_stream2_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
+// producer / consumer streaming kernel (conv_stream_pc.hip, ConvTile::kind == 3): eight waves in two groups that alternate
+// over the units - one multiplies while the other finishes the previous unit and requests operands; two halo buffers
+bool conv_stream_pc_supports(const ConvPlan& p);
+size_t conv_stream_pc_lds(const ConvPlan& p, int buf_bytes, int n_wslots);
+int conv_stream_pc_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 // 1x1 convs without a staged tile (conv_direct.hip, ConvTile::kind == 4): B fragments straight from global memory,
 // weights in registers; conv_direct_mb = cout tiles per wave, 0 when the layer is not one the kernel takes
 // conv 1x1 64 -> 256 + residual + ReLU and the conv 1x1 256 -> 64 + ReLU that reads its output, as one kernel (conv_pair.hip)

@@ -159,41 +159,45 @@ def test_direct_1x1_kernel_is_bit_identical(nat, case):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
-STREAM2_CASES = [
-    # cin, cout, stride, H, W, N, residual: shapes the second-generation streaming kernel offers launch shapes for
-    # (resident weights or stride 2), several units per workgroup, partial tiles, no residual / no ReLU paths
-    (96, 96, 1, 80, 80, 8, True), (96, 96, 1, 37, 51, 3, True), (96, 96, 1, 40, 32, 3, False), (48, 48, 1, 64, 80, 4, True),
-    (48, 96, 2, 80, 80, 4, False), (48, 192, 2, 48, 80, 3, False),
+STREAM_PC_CASES = [
+    # cin, cout, H, W, N, residual: 3x3 stride-1 layers of the 96 / 192 / 384-channel branches (and 48 -> 48: one channel
+    # chunk), resident weights and the weight ring, one unit per workgroup up to five (the bench's 96 -> 96 at 80 x 80,
+    # batch 32), partial tiles at the image border, no residual / no ReLU, cin != cout
+    (96, 96, 80, 80, 32, True), (96, 96, 80, 80, 8, False), (96, 96, 37, 51, 3, True), (96, 96, 40, 32, 3, False),
+    (192, 192, 40, 40, 32, True), (192, 192, 24, 40, 5, False), (384, 384, 20, 20, 32, True), (384, 384, 12, 20, 3, False),
+    (96, 192, 40, 40, 4, False), (192, 96, 33, 17, 2, True), (48, 48, 64, 80, 4, True), (48, 96, 16, 20, 1, False),
 ]
 
 
-@pytest.mark.parametrize("case", STREAM2_CASES, ids=lambda c: "stream2_%d-%d_s%d_%dx%d_n%d" % c[:6])
-def test_second_generation_streaming_kernel_is_bit_identical(nat, case):
-    """csrc/conv_stream.hip, conv_stream2_kernel (opt-in: option "stream_v2"): tiles staged through the loader waves'
-    registers, the loaders run the residual / ReLU / store phase.  An experiment that did not beat the first kernel
-     and is never selected by default; where it offers launch shapes it must give the same bits."""
-    cin, cout, s, H, W, N, use_res = case
+@pytest.mark.parametrize("case", STREAM_PC_CASES, ids=lambda c: "pc_%d-%d_%dx%d_n%d_%d" % c)
+def test_producer_consumer_streaming_kernel_is_bit_identical(nat, case):
+    """csrc/conv_stream_pc.hip (ConvTile kind 3; option "stream_pc": 0 = never, 1 = one more family of launch shapes for
+    the autotuner (default), 2 = the only streaming kernel, also for un-tuned launches as here): two wave groups alternate
+    over the units, the finishing group turns the accumulators into row pieces with v_permlane16_swap and requests the
+    operands.  Same k order and rounding points as conv_stream_kernel: the same bits, whatever the number of units per
+    workgroup, with partial tiles, with and without residual / ReLU"""
+    cin, cout, H, W, N, use_res = case
     g = torch.Generator().manual_seed(cin + cout + H)
     x = torch.randn(N, H, W, cin, generator=g).half().to("cuda:0")
     w = ((torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5).half().contiguous().numpy()
     a = (torch.rand(cout, generator=g) * 0.4 + 0.8).numpy()
     b = (torch.randn(cout, generator=g) * 0.1).numpy()
-    Ho, Wo = H // s, W // s
-    res = torch.randn(N, Ho, Wo, cout, generator=g).half().to("cuda:0") if use_res else None
+    res = torch.randn(N, H, W, cout, generator=g).half().to("cuda:0") if use_res else None
     fp = ctypes.POINTER(ctypes.c_float)
     L = nat.lib()
     outs = []
     try:
-        for v2 in (0, 2):
-            nat.check(L.rtpe_set_option(b"stream_v2", v2))
-            y = torch.full((N, Ho, Wo, cout), float("nan"), dtype=torch.float16, device="cuda:0")
+        for pc in (0, 2):
+            nat.check(L.rtpe_set_option(b"stream_pc", pc))
+            y = torch.full((N, H, W, cout), float("nan"), dtype=torch.float16, device="cuda:0")
             flags = (nat.F_RELU if use_res else 0) | nat.F_ROUND_CONV
             nat.check(L.rtpe_conv2d_nhwc(x.data_ptr(), N, H, W, cin, w.ctypes.data, a.ctypes.data_as(fp), b.ctypes.data_as(fp),
-                                         cout, 3, s, flags, res.data_ptr() if use_res else None, y.data_ptr(),
+                                         cout, 3, 1, flags, res.data_ptr() if use_res else None, y.data_ptr(),
                                          nat.stream_ptr(torch.device("cuda:0"))))
+            torch.cuda.synchronize()
             outs.append(y.cpu())
     finally:
-        nat.check(L.rtpe_set_option(b"stream_v2", 0))
+        nat.check(L.rtpe_set_option(b"stream_pc", 1))
     assert not torch.isnan(outs[1].float()).any()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
@@ -435,6 +439,13 @@ def _alt(case, stride):
     return None
 
 
+def _alt_full_max(case):
+    """full-tensor max |second run - first run| of the reference per map group (heat maps, tags, refined), or None"""
+    ss = _selfspread()
+    k = case + "_stats_mkldnn_off"
+    return [float(v) for v in ss[k][:, 0]] if k in ss else None
+
+
 def _emulated(sd, x, key):
     """the half wrapper with the same rounding points computed by OTHER kernels on the CPU (fp32 convolutions +
     explicit fp16 roundings, oracle/hrnet_ref.py ``half="emulate"``): a second witness of how far two faithful
@@ -445,7 +456,7 @@ def _emulated(sd, x, key):
     return _EMU[key]
 
 
-def _check_maps(got, want, emu, name, teacher_span, alt=None):
+def _check_maps(got, want, emu, name, teacher_span, alt=None, own_full_max=None):
     """``got`` (HIP) against ``want`` (the reference: PyTorch-CPU's native half path), bounded by the reference's
     distance from ITSELF.
 
@@ -457,7 +468,9 @@ def _check_maps(got, want, emu, name, teacher_span, alt=None):
     up to 0.92) max 2.93e-3, 99.57 %; W2's tag maps (+-3.1: one fp16 step = 2e-3) max 1.1e-2, 43.7 %.  "Every element
     within 1e-3" is therefore not a property the reference has against itself (declared deviation).
     Asserted when ``alt`` exists (every fixture of the w48 teacher with W0 / W2 weights):
-      * max |HIP - reference| <= 1.25 x max |reference' - reference| + one fp16 step of the map's range;
+      * max |HIP - reference| <= 1.25 x max |reference' - reference|, the reference's max taken over the FULL tensor
+        (``own_full_max``, stored with every self-spread case; HIP's side may be a strided sample of it) - no
+        allowance of an fp16 step on top;
       * the fraction of elements within 1e-3 is not lower than the reference's own by more than 0.1 percentage
         points (maps of the teacher's span) / 2 points (maps where one fp16 step exceeds 1e-3: there the fraction
         is in effect the share of bit-identical elements);
@@ -478,8 +491,9 @@ def _check_maps(got, want, emu, name, teacher_span, alt=None):
     if teacher_span:
         assert rng <= 1.0, "%s: expected maps of the teacher's span, got range %.2f" % (name, rng)
     if alt is not None:
-        assert err.max() <= 1.25 * own.max() + step, "%s: max error %.3e vs %.3e of the reference against itself" % (
-            name, err.max(), own.max())
+        own_max = max(own.max(), own_full_max or 0.0)
+        assert err.max() <= 1.25 * own_max + (0.0 if own_full_max else step), \
+            "%s: max error %.3e vs %.3e of the reference against itself" % (name, err.max(), own_max)
         assert f_hip >= f_own - (0.001 if step <= 0.5 * HEATMAP_TOL else 0.02), "%s: %.5f within 1e-3 vs %.5f" % (name, f_hip, f_own)
         assert err.mean() <= 1.15 * own.mean() + 1e-6, "%s: mean error %.3e vs %.3e" % (name, err.mean(), own.mean())
     assert err.max() <= 1.5 * ref.max() + step, "%s: max error %.3e vs %.3e between CPU implementations" % (
@@ -489,19 +503,20 @@ def _check_maps(got, want, emu, name, teacher_span, alt=None):
     return err.max()
 
 
-def _check_outputs(preds, refined, want_preds, want_refined, emu, name, teacher_span, sl=None, alt=None):
+def _check_outputs(preds, refined, want_preds, want_refined, emu, name, teacher_span, sl=None, alt=None, full_max=None):
     """heat-map channels and tag channels separately (BASELINE.json's tolerance is on the heat maps); ``sl``: the
     strided sample the golden holds; ``alt``: (preds, refined) of the reference's second run, sampled like the golden"""
     ep, er = emu
     if sl is not None:
         preds, refined, ep, er = preds[sl], refined[sl], ep[sl], er[sl]
     ap, ar = alt if alt is not None else (None, None)
+    fm = full_max if (full_max is not None and alt is not None) else (None, None, None)
     _check_maps(preds[:, :17], want_preds[:, :17], ep[:, :17], name + " heat maps (preds[:, :17])", teacher_span,
-                None if ap is None else ap[:, :17])
-    _check_maps(refined, want_refined, er, name + " refined", teacher_span, ar)
+                None if ap is None else ap[:, :17], fm[0])
+    _check_maps(refined, want_refined, er, name + " refined", teacher_span, ar, fm[2])
     tag_span = teacher_span and np.abs(want_preds[:, 17:]).max() <= 1.0
     _check_maps(preds[:, 17:], want_preds[:, 17:], ep[:, 17:], name + " tags (preds[:, 17:])", tag_span,
-                None if ap is None else ap[:, 17:])
+                None if ap is None else ap[:, 17:], fm[1])
 
 
 @pytest.mark.parametrize("variant", ["W0", "W1", "W2"])
@@ -520,7 +535,8 @@ def test_forward_small_vs_oracle_and_golden(nat, teacher, golden_dir, variant):
         g = np.load(os.path.join(golden_dir, "hrnet_small.npz"))
         gp, gr = g[variant + "_half_preds"], g[variant + "_half_refined"]
     _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), gp.astype(np.float32), gr.astype(np.float32), emu,
-                   variant + " vs reference (golden)", span, alt=_alt(variant + "_small", 0) if variant != "W1" else None)
+                   variant + " vs reference (golden)", span, alt=_alt(variant + "_small", 0),
+                   full_max=_alt_full_max(variant + "_small"))
     # the oracle on THIS host's CPU (the restatement of the same path; bit-equal to the golden in the build container)
     op, orf = hrnet_ref.hrnet_forward(sd, x, half=True)
     _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), op.numpy(), orf.numpy(), emu, variant + " vs oracle", span)
@@ -643,8 +659,11 @@ def test_forward_640_w1_declared_deviation(nat, teacher, golden_dir):
         preds, refined = m(x.to("cuda:0"))
     g = np.load(os.path.join(golden_dir, "hrnet_640.npz"))
     sl = (slice(None), slice(None), slice(None, None, 8), slice(None, None, 8))
+    alt = _alt("W1_640", 8)
+    assert alt is not None
     _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), g["preds_s8"].astype(np.float32),
-                   g["refined_s8"].astype(np.float32), _emulated(sd, x, ("W1", 640)), "W1 640", False, sl)
+                   g["refined_s8"].astype(np.float32), _emulated(sd, x, ("W1", 640)), "W1 640", False, sl, alt,
+                   _alt_full_max("W1_640"))
     assert abs(float(preds.double().abs().sum()) - float(g["preds_abs"])) < 2e-3 * float(g["preds_abs"])
     assert abs(float(refined.double().abs().sum()) - float(g["refined_abs"])) < 2e-3 * float(g["refined_abs"])
 
@@ -657,10 +676,12 @@ def batch32():
 def _check_640_samples(g, i, preds, refined, emu, name):
     st = 4 if i == 0 else 8
     sl = (slice(None), slice(None), slice(None, None, st), slice(None, None, st))
-    alt = _alt("%s_img%d" % (name.split()[0], i), st)
+    case = "%s_img%d" % (name.split()[0], i)
+    alt = _alt(case, st)
     assert alt is not None
     _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), g["img%d_preds_s%d" % (i, st)].astype(np.float32),
-                   g["img%d_refined_s%d" % (i, st)].astype(np.float32), emu, "%s image %d" % (name, i), True, sl, alt)
+                   g["img%d_refined_s%d" % (i, st)].astype(np.float32), emu, "%s image %d" % (name, i), True, sl, alt,
+                   _alt_full_max(case))
     for t, key in ((preds, "img%d_preds_abs" % i), (refined, "img%d_refined_abs" % i)):
         assert abs(float(t.double().abs().sum()) - float(g[key])) < 1e-3 * float(g[key])
 
@@ -1092,7 +1113,7 @@ def _compare_loop_body(g, prefix, model, sd, t, h, w, tag_tol):
     assert alt is not None, case
     _check_outputs(preds.cpu().numpy(), refined.cpu().numpy(), g[prefix + "preds_s8"].astype(np.float32),
                    g[prefix + "refined_s8"].astype(np.float32), _emulated(sd, t.cpu(), (prefix, tuple(t.shape))),
-                   prefix, True, sl, alt)
+                   prefix, True, sl, alt, _alt_full_max(case))
     tag_err = np.abs(preds.cpu().numpy()[:, 17:, ::8, ::8] - g[prefix + "preds_s8"][:, 17:].astype(np.float32)).max()
     assert tag_err <= tag_tol, tag_err
     # (2)
@@ -1153,6 +1174,9 @@ def _compare_loop_body(g, prefix, model, sd, t, h, w, tag_tol):
     # (4)
     ref_people, ref_scores = g[prefix + "final"], g[prefix + "scores"]
     print("%s people: reference %d, GPU %d" % (prefix, len(ref_people), len(res[0][0])))
+    # grouping noise maps is chaotic (one candidate that flips under the map tolerance can split or merge a person), but
+    # not arbitrary: the counts agree to +-2 of 30 ... 217 on every case
+    assert abs(len(res[0][0]) - len(ref_people)) <= 2, (prefix, len(ref_people), len(res[0][0]))
     if identical:
         assert len(res[0][0]) == len(ref_people)
         np.testing.assert_allclose(np.sort(np.array(res[0][1], np.float32)), np.sort(ref_scores), atol=2 * tol)

@@ -377,13 +377,40 @@ def test_stream_kernel_register_window_is_not_allocated(built, tmp_path):
     dis = subprocess.run([llvm + "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
     mine = re.compile(r"global_load_dwordx4 v\[2\d\d:2\d\d\], v\d+, s\[|v_pk_add_f16 v\d+, v\d+, v2\d\d\b")
     n_window = 0
-    in_v1 = False                       # the second-generation kernel (conv_stream2_kernel) has no window: skipped
+    in_v1 = False
     for line in dis.splitlines():
         label = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if label:
             in_v1 = "conv_stream_kernel" in label.group(1)
             continue
         if not in_v1:
+            continue
+        code = line.split("//")[0]
+        hi = 0
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", code):
+            hi = max(hi, int(m.group(2)))
+        for m in re.finditer(r"\bv(\d+)\b", code):
+            hi = max(hi, int(m.group(1)))
+        if hi >= 224:
+            assert mine.search(code), "compiler-allocated register in the window: " + code.strip()
+            n_window += 1
+    assert n_window > 0
+    # the producer / consumer kernel (conv_stream_pc.hip) keeps its residual pieces in the same window: buffer loads into
+    # v[224:255] and the packed adds that read them are the only instructions that may name those registers
+    obj = shutil.copy(os.path.join(os.path.dirname(built.LIB_PATH), "build", "conv_stream_pc.hip.o"), str(tmp_path / "p.o"))
+    fat, co = str(tmp_path / "p.fatbin"), str(tmp_path / "p.co")
+    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, str(tmp_path / "p2.o")], check=True)
+    subprocess.run([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--input=" + fat, "--output=" + co], check=True)
+    dis = subprocess.run([llvm + "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    mine = re.compile(r"buffer_load_dwordx4 v\[2\d\d:2\d\d\], v\d+, s\[\d+:\d+\], s\d+ offen|v_pk_add_f16 v\d+, v\d+, v2\d\d\b")
+    n_window, in_pc = 0, False
+    for line in dis.splitlines():
+        label = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if label:
+            in_pc = "conv_stream_pc_kernel" in label.group(1)
+            continue
+        if not in_pc:
             continue
         code = line.split("//")[0]
         hi = 0

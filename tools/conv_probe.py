@@ -76,5 +76,9 @@ def run(case, reps=3):
 
 
 if __name__ == "__main__":
+    # RTPE_PROBE_OPTS="stream_pc=2,direct_1x1=0": tuning options (rtpe_set_option) for this run
+    for kv in filter(None, os.environ.get("RTPE_PROBE_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        nat.check(nat.lib().rtpe_set_option(k.encode(), int(v)))
     for c in (sys.argv[1:] or DEFAULT):
         run(c)
