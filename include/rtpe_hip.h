@@ -254,8 +254,9 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * the fused BasicBlock kernel streams its weights through a 3-slot LDS ring instead of keeping them resident
  * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc").  "stream_pc" (env RTPE_STREAM_PC): the
  * producer / consumer streaming conv kernel for the 3x3 stride-1 convs with 48-channel chunks (csrc/conv_stream_pc.hip: two
- * wave groups alternate over the units, one multiplies while the other finishes the previous unit) is 0 = never used,
- * 1 = one more family of launch shapes for the autotuner (default),
+ * wave groups alternate over the units, one multiplies while the other finishes the previous unit) is 0 = never used
+ * (default: measured equal to or slower than the first streaming kernel on every layer class, DESIGN.md section 4 "Round 4"),
+ * 1 = one more family of launch shapes for the autotuner,
  * 2 = the only streaming kernel (also for un-tuned launches: the layer-level tests run it this way).  "direct_1x1" (env
  * RTPE_DIRECT_1X1): the 1x1 conv kernel without a staged input tile (csrc/conv_direct.hip) is 0 = never used, 1 = one more launch
  * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved).  "lanes" (env RTPE_LANES): the

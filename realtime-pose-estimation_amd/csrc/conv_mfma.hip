@@ -134,7 +134,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int c = kk - tap * a.cc;
     const int tyy = (a.tapw == 3) ? (tap * 11 >> 5) : (a.tapw == 2 ? (tap >> 1) : (a.tapw == 5 ? (tap * 13 >> 6) : 0));
     const int txx = tap - tyy * a.tapw;
-    tapoff[i] = tyy * a.dil * a.rowb + txx * a.dil * a.pstride + c * ES;
+    // (stride 2, de-interleaved columns: tap column txx of output column ox is input column 2 ox + txx = LDS column
+    // (txx & 1) * n_even + ox + (txx >> 1))
+    const int colslot = a.deint ? (txx & 1) * a.n_even + (txx >> 1) : txx * a.dil;
+    tapoff[i] = tyy * a.dil * a.rowb + colslot * a.pstride + c * ES;
   }
 
   // per-lane pixel of each N tile
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const uint32_t p = (wv * NT + nt) * 16 + r;
     const uint32_t oy = fdiv(p, a.div_tw);
     const uint32_t ox = p - oy * a.tw;
-    pixbase[nt] = (int)(oy * a.in_mul * a.rowb + ox * a.in_mul * a.pstride);
+    pixbase[nt] = (int)(oy * a.in_mul * a.rowb + ox * (a.deint ? 1 : a.in_mul) * a.pstride);
   }
 
   float4v acc[MT][NT];
@@ -213,7 +216,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const uint32_t rem = L - hy * ((uint32_t)a.rowb >> 4);
         const uint32_t hx = fdiv(rem, a.div_ps16);
         const uint32_t s = rem - hx * ((uint32_t)a.pstride >> 4);
-        const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
+        // LDS column hx holds input column: even ones first, then the odd ones (stride 2) / itself
+        const int hxs = a.deint ? ((int)hx < a.n_even ? 2 * (int)hx : 2 * ((int)hx - a.n_even) + 1) : (int)hx;
+        const int iy = iy0 + (int)hy, ix = ix0 + hxs;
         const bool ok = (int)hx < a.halo_w && (int)s < slots && (unsigned)iy < (unsigned)a.H_in &&
                         (unsigned)ix < (unsigned)a.W_in && cbase + (int)s * EPS < a.cin;
         const uint32_t voff = ok ? (uint32_t)((iy * a.W_in + ix) * a.in_ld + cbase + (int)s * EPS) * (uint32_t)ES : 0x80000000u;
@@ -234,7 +239,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const uint32_t hx = fdiv(q, a.div_slots);
         const uint32_t s = q - hx * slots;
         const int iy = iy0 + (int)hy, ix = ix0 + (int)hx;
-        dst[u] = idx < total ? (int)(hy * a.rowb + hx * a.pstride + s * 16) : -1;
+        const uint32_t hxl = a.deint ? ((hx & 1u) ? (uint32_t)a.n_even + (hx >> 1) : (hx >> 1)) : hx;   // LDS column of input column hx
+        dst[u] = idx < total ? (int)(hy * a.rowb + hxl * a.pstride + s * 16) : -1;
         v[u] = make_uint4(0, 0, 0, 0);
         if (idx < total && (unsigned)iy < (unsigned)a.H_in && (unsigned)ix < (unsigned)a.W_in &&
             cbase + (int)s * EPS < a.cin)
@@ -493,13 +499,22 @@ void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w_in, v
 // next row, in_mul * rowb - tw * in_mul * pstride bytes further than the next pixel would be: the row pitch is
 // padded until that difference is a multiple of the 256-byte bank period (model: 6.4 -> 4.0 LDS cycles per read
 // for 20-wide tiles, 4.8 -> 4.0 for 40-wide ones).
-int conv_row_pitch(const ConvPlan& p, int tw) {
+int conv_row_pitch(const ConvPlan& p, int tw, int kind) {
   const int hw = (tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   int rb = hw * p.pstride;
   static const int pad = getenv("RTPE_CONV_ROWPAD") ? atoi(getenv("RTPE_CONV_ROWPAD")) : 1;
+  // (de-interleaved stride-2 tiles of the one-workgroup-per-tile kernel: consecutive output pixels are pstride apart)
+  const int step = conv_deint(p, kind) ? p.pstride : p.in_mul * p.pstride;
   if (pad && p.esize == 2 && tw % 16 != 0)
-    while ((p.in_mul * rb - tw * p.in_mul * p.pstride) % 256 != 0) rb += 16;
+    while ((p.in_mul * rb - tw * step) % 256 != 0) rb += 16;
   return rb;
+}
+
+// stride-2 convs on the one-workgroup-per-tile kernel (kind 0) stage their tiles with the even input columns first
+// (RTPE_S2_DEINT=0: in input order, the B-operand reads of 16 consecutive output pixels then hit every bank four times)
+bool conv_deint(const ConvPlan& p, int kind) {
+  static const int on = getenv("RTPE_S2_DEINT") ? atoi(getenv("RTPE_S2_DEINT")) : 1;
+  return on && kind == 0 && p.in_mul == 2 && p.dil == 1;
 }
 
 struct TileCand { int waves, nt, th, tw; };
@@ -516,7 +531,7 @@ static const TileCand kCands[] = {
 
 static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
   const int hh = (th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
-  const size_t in_tile = (size_t)hh * conv_row_pitch(p, tw);
+  const size_t in_tile = (size_t)hh * conv_row_pitch(p, tw, 0);
   const size_t out_tile = (size_t)waves * nt * 16 * (p.mt * 16 * p.esize + 16);   // epilogue transpose buffer
   return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
 }
@@ -530,7 +545,7 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != 2 || p.n_cchunks != 1)) return false;
   const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
   if (hw * 6 > 256) return false;                        // a halo row is at most 4 DMA instructions
-  const size_t in_tile = (size_t)hh * conv_row_pitch(p, c.tw);
+  const size_t in_tile = (size_t)hh * conv_row_pitch(p, c.tw, 2);
   const size_t out_tile = (size_t)c.waves * c.nt * 16 * (p.mt * 32 + 16);
   size_t buf = in_tile > out_tile ? in_tile : out_tile;
   buf = (buf + 255) / 256 * 256;
@@ -561,7 +576,7 @@ static bool stream_pc_tile(const ConvPlan& p, const TileCand& c, int N, int H_po
   if (!conv_stream_pc_supports(p) || c.waves != 4 || (c.nt != 4 && c.nt != 5)) return false;
   const int hh = c.th + 2, hw = c.tw + 2;
   if (hw * 6 > 256 || c.th > 255 || c.tw > 255) return false;
-  size_t buf = (size_t)hh * conv_row_pitch(p, c.tw);
+  size_t buf = (size_t)hh * conv_row_pitch(p, c.tw, 2);
   buf = (buf + 255) / 256 * 256;
   const bool resident = want_resident && p.n_cchunks <= 2 && conv_stream_pc_lds(p, (int)buf, 2 * p.n_cchunks) <= 160 * 1024;
   if (want_resident != resident) return false;
@@ -694,7 +709,9 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->dil = p.dil;
   a->halo_h = (t.th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   a->halo_w = (t.tw - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
-  a->rowb = conv_row_pitch(p, t.tw);
+  a->rowb = conv_row_pitch(p, t.tw, t.kind);
+  a->deint = conv_deint(p, t.kind) ? 1 : 0;
+  a->n_even = (a->halo_w + 1) >> 1;
   a->div_rowb16 = make_fastdiv((uint32_t)a->rowb >> 4);
   a->div_ps16 = make_fastdiv((uint32_t)p.pstride >> 4);
   {   // buffer bounds of one image of the input view for the LDS-DMA staging (the caller has set N, H_in, W_in, in_ld)
@@ -717,7 +734,7 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
-  if (t.kind == 3) {
+  if (t.kind == 3 || t.kind == 2) {
     static const int pcf = RTPE_DIAG_ENV_INT("RTPE_PC_FLAGS", 0);
     a->pc_flags = pcf;
   }

@@ -142,6 +142,20 @@ conv_stream_pc_kernel(const ConvArgs a) {
     const int row_lo = iy0 < 0 ? -iy0 : 0, row_hi = a.H_in - iy0;
     const int ra = a.halo_h * part / nparts, rb = a.halo_h * (part + 1) / nparts;
     const int r0 = ra + (rb - ra) * half / nhalves, r1 = ra + (rb - ra) * (half + 1) / nhalves;
+    if (a.pc_flags & 16) {                               // piece-major order (conv_stream.hip, fire)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < krow && k * 64 + lane < rowslots) {
+          for (int r = r0; r < r1; ++r) {
+            const bool row_ok = r >= row_lo && r < row_hi;
+            const int soff = row_ok ? soff0 + r * soff_row : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(buf + r * a.rowb + k * 1024), 16,
+                                                     (int)(row_ok ? voff[k] : kOor), soff, 0, 0);
+          }
+        }
+      }
+      return (r1 - r0) * krow;
+    }
     for (int r = r0; r < r1; ++r) {
       const bool row_ok = r >= row_lo && r < row_hi;
       const int soff = row_ok ? soff0 + r * soff_row : 0;
@@ -285,20 +299,23 @@ conv_stream_pc_kernel(const ConvArgs a) {
   int pend = -1;                                         // the unit whose sums wait in `acc` (this group)
   const bool wt = RTPE_WT_STORES && !(a.pc_flags & 4);   // write-through row stores (rtpe_common.h store16_wt)
 
+  // residual rows of unit u -> the register window; NP buffer loads, nobody waits here
+  auto load_res = [&](int u) {
+    const UnitS q = unit_scalars(u);
+    const int rsoff = q.rsoff;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const uint32_t vo = piece_off(it, (uint32_t)a.res_ld, q.hy, q.hx);
+      if (it == 0) asm volatile("s_nop 4" ::: "memory");
+      RTPE_PC_RES_ALL(RTPE_PC_RES_LOAD)
+    }
+  };
   // The whole epilogue of the pending unit: BN (+ residual) (+ ReLU) on the accumulators, row pieces by lane-row swaps,
-  // stores.  Returns the number of vector-memory operations issued behind the last wait (the stores).
-  auto epilogue = [&]() {
+  // stores.  `younger`: vector-memory operations this wave has issued behind the unit's residual loads.  Returns the
+  // stores issued.
+  auto epilogue = [&](int younger) {
     const UnitS pus = unit_scalars(pend);
     pend = -1;
-    if (use_res) {
-      const int rsoff = pus.rsoff;
-#pragma unroll
-      for (int it = 0; it < NP; ++it) {
-        const uint32_t vo = piece_off(it, (uint32_t)a.res_ld, pus.hy, pus.hx);
-        if (it == 0) asm volatile("s_nop 4" ::: "memory");
-        RTPE_PC_RES_ALL(RTPE_PC_RES_LOAD)
-      }
-    }
     float4v al[MT], be[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -333,7 +350,7 @@ conv_stream_pc_kernel(const ConvArgs a) {
       const u32x2 o = bn(acc[2][NT - 1], 2);
       piece[NP - 1] = swap_pair(o, o);
     }
-    if (use_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (use_res) wait_vmcnt(younger);
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       int4v w = piece[it];
@@ -411,15 +428,21 @@ conv_stream_pc_kernel(const ConvArgs a) {
         SSTAMP(c0);
         RTPE_SBARRIER();                                   // M(s): buffer (s + 1) & 1 and ring slot (2 s + 2) % 3 are free
         SSTAMP(c1);
-        int n_iv = 0;
+        int n_iv = 0, n_t = 0;
         const bool more = s + 1 < S && !(a.ablate & 4);
-        if (more) n_iv += issue_tile(s + 1, wi, 4, 0, split ? 2 : 1);
+        if (more) n_t = issue_tile(s + 1, wi, 4, 0, split ? 2 : 1);
+        n_iv = n_t;
         if (!resident && 2 * s + 2 < 2 * S) n_iv += issue_w(2 * s + 2, wi, 4);
         if (resident) n_iv = 0;                            // (the tile must have landed at the next barrier: count what follows it)
         SSTAMP(c2);
-        if (cci == 0 && pend >= 0) {
-          const int n_st = epilogue();
-          n_iv = use_res ? n_st : n_iv + n_st;             // (the wait for the residual rows has drained everything before it)
+        if (cci == 0) {
+          // finish this group's previous unit
+          // (the residual rows are requested HERE, behind the tile of the next stage, not a unit ahead: requested early they
+          // sit in the CU's in-order memory pipeline in front of the next tile requests - 44.6 -> 49.6 us at C = 96)
+          if (pend >= 0) {
+            if (use_res) { load_res(pend); n_iv = 0; }     // (the epilogue waits for them: everything before has landed too)
+            n_iv += epilogue(0);
+          }
         }
         SSTAMP(c3);
         if (!resident) {
@@ -441,7 +464,10 @@ conv_stream_pc_kernel(const ConvArgs a) {
 #ifdef RTPE_CONV_STAMPS
   SSTAMP(c0);
 #endif
-  if (pend >= 0) epilogue();
+  if (pend >= 0) {
+    if (use_res) load_res(pend);
+    epilogue(0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RTPE_CONV_STAMPS
   if (a.dbg != nullptr && lane == 0) {

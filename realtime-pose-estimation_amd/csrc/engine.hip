@@ -80,7 +80,7 @@ namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
 static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", ""};
 static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", ""};
-static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 0};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 0};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {

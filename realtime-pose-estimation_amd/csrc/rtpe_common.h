@@ -159,6 +159,10 @@ struct ConvArgs {
   int buf_bytes;         // streaming kernel: bytes of one LDS tile buffer
   int n_bufs;            // streaming kernel: halo tile buffers (2 or 3)
   int n_wslots;          // streaming kernel: weight half-stage slots in LDS (3: ring, 2*n_cchunks: resident)
+  int deint;             // one-workgroup-per-tile kernel, stride 2: the staged tile keeps the even input columns of a row
+                         // first, then the odd ones (n_even = number of even columns): consecutive OUTPUT pixels of a tap are
+                         // then consecutive LDS pixels, as with stride 1, and the B-operand reads are bank-conflict free
+  int n_even;
   int pc_flags;          // streaming pc kernel: 1 = the finishing group runs at a higher wave priority, 2 = the tile of the next
                          // stage is requested in two halves around the mid-stage barrier (weight ring only), 4 = plain instead of
                          // write-through row stores
@@ -200,7 +204,8 @@ ConvPlan conv_make_plan(const ConvGeom& g);
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct = true);
 // LDS bytes per row of the staged input tile of a tw-wide output tile: halo_w * pstride, padded (fp16) so that a
 // 16-pixel MFMA column tile which wraps to the next output row keeps the bank pattern of consecutive pixels
-int conv_row_pitch(const ConvPlan& p, int tw);
+int conv_row_pitch(const ConvPlan& p, int tw, int kind);
+bool conv_deint(const ConvPlan& p, int kind);
 void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector<ConvTile>* out);
 // pack fp16 weights (host) into fragment order; w is OIHW (IOHW 4x4 for deconv classes)
 void conv_pack_weights(const ConvGeom& g, const ConvPlan& p, const void* w, void* packed);

@@ -171,8 +171,8 @@ STREAM_PC_CASES = [
 
 @pytest.mark.parametrize("case", STREAM_PC_CASES, ids=lambda c: "pc_%d-%d_%dx%d_n%d_%d" % c)
 def test_producer_consumer_streaming_kernel_is_bit_identical(nat, case):
-    """csrc/conv_stream_pc.hip (ConvTile kind 3; option "stream_pc": 0 = never, 1 = one more family of launch shapes for
-    the autotuner (default), 2 = the only streaming kernel, also for un-tuned launches as here): two wave groups alternate
+    """csrc/conv_stream_pc.hip (ConvTile kind 3; option "stream_pc": 0 = never (default), 1 = one more family of launch
+    shapes for the autotuner, 2 = the only streaming kernel, also for un-tuned launches as here): two wave groups alternate
     over the units, the finishing group turns the accumulators into row pieces with v_permlane16_swap and requests the
     operands.  Same k order and rounding points as conv_stream_kernel: the same bits, whatever the number of units per
     workgroup, with partial tiles, with and without residual / ReLU"""
@@ -197,7 +197,7 @@ def test_producer_consumer_streaming_kernel_is_bit_identical(nat, case):
             torch.cuda.synchronize()
             outs.append(y.cpu())
     finally:
-        nat.check(L.rtpe_set_option(b"stream_pc", 1))
+        nat.check(L.rtpe_set_option(b"stream_pc", 0))
     assert not torch.isnan(outs[1].float()).any()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 

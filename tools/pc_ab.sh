@@ -10,7 +10,9 @@ lib=$root/realtime-pose-estimation_amd/librtpe_diag.so
 [ -f $lib ] || lib=$root/realtime-pose-estimation_amd/librtpe_hip.so
 cd /tmp && export TMPDIR=/tmp
 export RTPE_LIBRARY=$lib
-RTPE_PROBE_OPTS=stream_pc=0 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $root/$out/prof_v1 -o t -- python3 $root/tools/conv_probe.py $cases > $root/$out/probe_v1.log 2>&1 || exit 1
+for f in ${V1_FLAGS:-0}; do
+  RTPE_PC_FLAGS=$f RTPE_PROBE_OPTS=stream_pc=0 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $root/$out/prof_v1_$f -o t -- python3 $root/tools/conv_probe.py $cases > $root/$out/probe_v1_$f.log 2>&1 || exit 1
+done
 for f in $flags; do
   RTPE_PC_FLAGS=$f RTPE_PROBE_OPTS=stream_pc=2 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $root/$out/prof_pc$f -o t -- python3 $root/tools/conv_probe.py $cases > $root/$out/probe_pc$f.log 2>&1 || exit 1
 done
