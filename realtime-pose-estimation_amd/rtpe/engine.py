@@ -220,7 +220,7 @@ class TeacherPipeline:
                         # lanes off for THIS call only (a per-call flag of the ABI: nothing process-wide is touched,
                         # and nothing stays changed while the generator is suspended or if it is abandoned)
                         prev_slot = set_workspace_slot(1 + k % n_fwd)
-                        prev_flags = set_forward_flags(FWD_NO_LANES)
+                        prev_flags = set_forward_flags(0 if os.environ.get("RTPE_STREAM_LANES", "0") == "1" else FWD_NO_LANES)
                         try:
                             with torch.cuda.stream(fs):
                                 preds, refined = on_forward(k, x) if on_forward is not None else self.model(x)
