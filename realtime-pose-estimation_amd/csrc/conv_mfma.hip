@@ -734,8 +734,8 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
-  if (t.kind == 3 || t.kind == 2) {
-    static const int pcf = RTPE_DIAG_ENV_INT("RTPE_PC_FLAGS", 0);
+  if (t.kind == 3) {
+    static const int pcf = RTPE_DIAG_ENV_INT("RTPE_PC_FLAGS", 0);     // diagnostic builds: 2 / 4 (rtpe_common.h)
     a->pc_flags = pcf;
   }
   static const int abl = RTPE_DIAG_ENV_INT("RTPE_STREAM_ABL", 0);

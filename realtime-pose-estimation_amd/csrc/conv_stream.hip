@@ -180,24 +180,6 @@ conv_stream_kernel(const ConvArgs a) {
       q.row_hi = a.H_in - iy0;                            // rows r with iy0 + r < H_in
     };
     auto fire = [&](const TileReq& q, int r0, int r1) {  // halo rows [r0, r1)
-      if (a.pc_flags & 16) {
-        // piece-major order: the k-th 1-KiB piece of every row, then the next piece of every row.  Consecutive pieces of
-        // a row share a 128-byte line (a row neither starts nor ends on one); issued back to back the second one meets
-        // that line while it is still on its way and the vector cache stalls until it has arrived
-        // (TCP_PENDING_STALL_CYCLES: 22-40 % of the cache's cycles in this kernel, profiles/r04_stream_mempath_counters.txt)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k * 64 < rowslots && k * 64 + lane < rowslots && !(a.ablate & 4)) {
-            for (int r = r0; r < r1; ++r) {
-              const bool row_ok = r >= q.row_lo && r < q.row_hi;
-              const int soff = row_ok ? q.soff0 + r * q.soff_row : 0;
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(q.buf + r * rowbytes + k * 1024), 16,
-                                                       (int)(row_ok ? q.voff[k] : 0x80000000u), soff, 0, 0);
-            }
-          }
-        }
-        return;
-      }
       for (int r = r0; r < r1; ++r) {
         const bool row_ok = r >= q.row_lo && r < q.row_hi;
         const int soff = row_ok ? q.soff0 + r * q.soff_row : 0;

@@ -142,20 +142,6 @@ conv_stream_pc_kernel(const ConvArgs a) {
     const int row_lo = iy0 < 0 ? -iy0 : 0, row_hi = a.H_in - iy0;
     const int ra = a.halo_h * part / nparts, rb = a.halo_h * (part + 1) / nparts;
     const int r0 = ra + (rb - ra) * half / nhalves, r1 = ra + (rb - ra) * (half + 1) / nhalves;
-    if (a.pc_flags & 16) {                               // piece-major order (conv_stream.hip, fire)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (k < krow && k * 64 + lane < rowslots) {
-          for (int r = r0; r < r1; ++r) {
-            const bool row_ok = r >= row_lo && r < row_hi;
-            const int soff = row_ok ? soff0 + r * soff_row : 0;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(buf + r * a.rowb + k * 1024), 16,
-                                                     (int)(row_ok ? voff[k] : kOor), soff, 0, 0);
-          }
-        }
-      }
-      return (r1 - r0) * krow;
-    }
     for (int r = r0; r < r1; ++r) {
       const bool row_ok = r >= row_lo && r < row_hi;
       const int soff = row_ok ? soff0 + r * soff_row : 0;
@@ -163,14 +149,9 @@ conv_stream_pc_kernel(const ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (k < krow) {
-          if (k * 64 + lane < rowslots) {
-            if (a.pc_flags & 8)                            // non-temporal: the halo rows are read once per CU
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + k * 1024), 16,
-                                                       (int)(row_ok ? voff[k] : kOor), soff, 0, 2);
-            else
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + k * 1024), 16,
-                                                       (int)(row_ok ? voff[k] : kOor), soff, 0, 0);
-          }
+          if (k * 64 + lane < rowslots)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + k * 1024), 16,
+                                                     (int)(row_ok ? voff[k] : kOor), soff, 0, 0);
         }
       }
     }
@@ -390,7 +371,6 @@ conv_stream_pc_kernel(const ConvArgs a) {
   for (int u = 0; u < n_units; ++u) {
     if ((u & 1) == grp) {
       // ===================================== multiplying group =====================================
-      if (a.pc_flags & 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -421,8 +401,6 @@ conv_stream_pc_kernel(const ConvArgs a) {
       pend = u;
     } else {
       // ===================================== finishing / requesting group =====================================
-      // (its instructions are few and the multiplying group waits for them at the next barrier: they go first)
-      if (a.pc_flags & 1) __builtin_amdgcn_s_setprio(2);
       for (int cci = 0; cci < ncc; ++cci) {
         const int s = (u << sh) + cci;
         SSTAMP(c0);

@@ -901,6 +901,14 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   a.relu = (flags & RTPE_F_RELU) ? 1 : 0;
   a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
   const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos);
+  // diagnostic builds, RTPE_PROBE_PLANE=1: time a streaming launch with plane-major views ([C/48][N][H][W][48], what the
+  // engine gives the inner tensors of the C >= 96 block chains) over the same bytes - the values are then meaningless
+  static const int probe_plane = RTPE_DIAG_ENV_INT("RTPE_PROBE_PLANE", 0);
+  if (probe_plane && (tile.kind == 2 || tile.kind == 3) && cin % 48 == 0 && cout % 48 == 0 && stride == 1) {
+    a.in_ld = 48; a.in_cs = (long long)N * H * W * 48;
+    a.out_ld = 48; a.out_cs = (long long)N * H * W * 48;
+    if (res != nullptr) { a.res_ld = 48; a.res_cs = (long long)N * H * W * 48; }
+  }
   conv_fill_args(g, p, tile, &a);
 #ifdef RTPE_CONV_STAMPS
   unsigned long long* dbg = nullptr;

@@ -163,9 +163,8 @@ struct ConvArgs {
                          // first, then the odd ones (n_even = number of even columns): consecutive OUTPUT pixels of a tap are
                          // then consecutive LDS pixels, as with stride 1, and the B-operand reads are bank-conflict free
   int n_even;
-  int pc_flags;          // streaming pc kernel: 1 = the finishing group runs at a higher wave priority, 2 = the tile of the next
-                         // stage is requested in two halves around the mid-stage barrier (weight ring only), 4 = plain instead of
-                         // write-through row stores
+  int pc_flags;          // streaming pc kernel, diagnostic switches: 2 = the tile of the next stage is requested in two halves
+                         // around the mid-stage barrier (weight ring only), 4 = plain instead of write-through row stores
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
   unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
