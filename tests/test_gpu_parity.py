@@ -938,17 +938,18 @@ def test_parse_lowres_with_adjust_or_refine_switched_off(nat, golden_dir, name):
         np.testing.assert_array_equal(np.array(scores, np.float32), g[key + "_scores"])
 
 
-def test_run_sharded_list_on_one_rank(nat, teacher):
+@pytest.mark.parametrize("S", [128, 640])
+def test_run_sharded_list_on_one_rank(nat, teacher, S):
     """configs[3]'s entry point (bench.py --list -> engine.run_sharded_list) on the one GPU a test box has: the
     100 names of the reference's assets/coco_minival2017_100.txt, batches of 32 with a short last batch (4), every
-    id back exactly once, and the records equal to what the pipeline returns for the same inputs"""
+    id back exactly once, and the records equal to what the pipeline returns for the same inputs - at 128 x 128 and at
+    the configuration's own 640 x 640"""
     from rtpe import engine
     m, sd = teacher("W0")
     names = [ln.strip() for ln in open(os.path.join(ROOT, "tests", "golden", "coco_minival2017_100.txt")) if ln.strip()]
     assert len(names) == 100
     pipe = engine.TeacherPipeline(m, device="cuda:0")
     gen = torch.Generator(device="cuda:0")
-    S = 128
     sizes, kept = [], {}
 
     def infer(part):
