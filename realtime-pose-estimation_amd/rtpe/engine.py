@@ -171,10 +171,10 @@ class TeacherPipeline:
             raise ValueError("in_flight must be 1..4, not %r" % (n_fwd,))
         fwd_streams = None
         if n_fwd > 1:
-            fwd_streams = self.__dict__.get("_forward_streams")
-            if fwd_streams is None or len(fwd_streams) < n_fwd:
-                fwd_streams = self._forward_streams = [torch.cuda.Stream(self.device) for _ in range(n_fwd)]
-            from .third_party.pose_higher_hrnet import FWD_NO_LANES, set_forward_flags, set_workspace_slot
+            from .third_party.pose_higher_hrnet import (FWD_NO_LANES, forward_streams, set_forward_flags,
+                                                        set_workspace_slot)
+            # per device, not per pipeline: slot 1 + i of a model is always on stream i, whoever loops over it
+            fwd_streams = forward_streams(self.device, n_fwd)
         side = None
         if mode == "side":
             side = self.__dict__.get("_decode_stream")
