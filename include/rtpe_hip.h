@@ -65,7 +65,8 @@ extern "C" {
 #define RTPE_DTYPE_F32 2
 
 const char* rtpe_last_error_string(void);
-/* ABI revision: 2 = rtpe_op_desc carries lane / region (sizeof 112 -> 120),
+/* ABI revision: 3 = tuned-shape records have 11 integers (RTPE_TUNED_INTS);
+ * 2 = rtpe_op_desc carries lane / region (sizeof 112 -> 120),
  * rtpe_hrnet_forward_flags exists.  A caller built against revision 1 must
  * not pass its descriptors to this library: check before rtpe_hrnet_create. */
 int rtpe_version(void);
@@ -289,10 +290,12 @@ int rtpe_rgb_to_alt(const float* src_nchw, int32_t N, int32_t H, int32_t W, int3
  * processes (the reference's cudnn.benchmark has to re-tune in every process).
  * RTPE_TUNED_INTS int32 per (op, parity class), 4 classes per op:
  * {pixel tiles/wave (0 = not tuned), waves, tile_h, tile_w, LDS bytes, kind, workgroups,
- * halo buffer bytes, halo buffers, weight slots}.  rtpe_hrnet_tuned_ints gives the array
- * length.  Import validates every record against the launch shapes this build offers for
+ * halo buffer bytes, halo buffers, weight slots, cout tiles per workgroup (0 = the whole
+ * packed block)}.  rtpe_hrnet_tuned_ints gives the array length (11 per record since
+ * revision 3 of the library, 10 before: size buffers from that call, not from the macro of
+ * an older header).  Import validates every record against the launch shapes this build offers for
  * the op at that shape and changes nothing if any record is foreign (RTPE_E_INVALID). */
-#define RTPE_TUNED_INTS 10
+#define RTPE_TUNED_INTS 11
 int rtpe_hrnet_tuned_ints(const rtpe_hrnet* h, int32_t* count);
 int rtpe_hrnet_export_tuned(const rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, int32_t* out, int32_t n);
 int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, const int32_t* in, int32_t n);

@@ -65,6 +65,20 @@ __device__ __forceinline__ float4v mfma_step<float>(const uint4& av, const uint4
   return acc;
 }
 
+// k chunks of weight fragments in flight per wave; a step keeps the matrix pipe busy for step_cycles (16 per fp16 tile
+// pair, 4 x 32 per fp32 one)
+#ifndef RTPE_WEIGHT_RING
+#define RTPE_WEIGHT_RING 0
+#endif
+__host__ __device__ constexpr int conv_weight_ring(int mt, int step_cycles) {
+  // ~1000 cycles of matrix work in flight, at most 8 chunks and 48 registers
+  int d = (1000 + step_cycles - 1) / step_cycles;
+  d = d > 8 ? 8 : d;
+  d = d > 12 / mt ? 12 / mt : d;
+  d = (step_cycles >= 256 && d > 2) ? 2 : d;     // 16 and more accumulator tiles: the registers are theirs
+  return RTPE_WEIGHT_RING ? RTPE_WEIGHT_RING : d < 1 ? 1 : d;
+}
+
 template <typename T, int MT, int NT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +118,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   // pieces meet in that L2 and HBM sees whole lines (4 separate launches: 1.5 GB of traffic per deconv for 0.46 GB
   // of tensors - every partial line was read back - PMC), and they share the input tile.
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t per_tile = (uint32_t)a.n_cb * (uint32_t)(a.n_cls > 0 ? a.n_cls : 1);
+  // m_split > 1: a packed cout block (MT * m_split cout tiles) is shared out to m_split workgroups of MT tiles each
+  // (small grids - batch 1, the /16 and /32 branches: three times the workgroups, a third of the k chain each; the
+  // k order of an output does not change)
+  const uint32_t m_split = a.m_split > 1 ? (uint32_t)a.m_split : 1u;
+  const uint32_t n_cbs = (uint32_t)a.n_cb * m_split;
+  const uint32_t per_tile = n_cbs * (uint32_t)(a.n_cls > 0 ? a.n_cls : 1);
   const uint32_t tq = slot / per_tile;
   // an XCD owns a CONTIGUOUS eighth of the row-major tile list: neighbouring tiles share their halo rows / columns and
   // the partial 128-byte lines at their edges in one L2 (tile t on XCD t % 8 fetched them once per XCD: 1.13-1.23 x
@@ -112,7 +131,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   uint32_t t = xcd * (gridDim.x / (8u * per_tile)) + tq;
   if (t >= (uint32_t)a.N * (uint32_t)(a.tiles_x * a.tiles_y)) return;      // grid padding (whole workgroup)
   const uint32_t sub = slot - tq * per_tile;
-  const int cls = (int)(sub / (uint32_t)a.n_cb);
+  const int cls = (int)(sub / n_cbs);
   const _Float16* const w_base = a.n_cls > 0 ? a.w_c[cls] : a.w;
   const int lo_y = a.n_cls > 0 ? a.lo_yc[cls] : a.lo_y, lo_x = a.n_cls > 0 ? a.lo_xc[cls] : a.lo_x;
   const int oy_add = a.n_cls > 0 ? a.oy_c[cls] : a.oy_add, ox_add = a.n_cls > 0 ? a.ox_c[cls] : a.ox_add;
@@ -121,7 +140,11 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   t -= n * tiles_xy;
   const uint32_t tyi = fdiv(t, a.div_tiles_x);
   const uint32_t txi = t - tyi * a.tiles_x;
-  const int cb = (int)(sub - (uint32_t)cls * (uint32_t)a.n_cb);
+  const uint32_t cbs = sub - (uint32_t)cls * n_cbs;
+  const int cb = (int)(cbs / m_split);                        // packed cout block
+  const int msel = (int)(cbs - (uint32_t)cb * m_split);       // this workgroup's share of it
+  const int mt_pack = MT * (int)m_split;
+  const int co_base = (cb * mt_pack + msel * MT) * 16;        // first output channel of this workgroup
   const int py0 = tyi * a.th, px0 = txi * a.tw;
   const int iy0 = py0 * a.in_mul + lo_y, ix0 = px0 * a.in_mul + lo_x;
 
@@ -157,11 +180,21 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
 
   const int n_k = a.n_cchunks * a.kc;  // total k chunks
-  const uint4* wfrag = reinterpret_cast<const uint4*>(w_base) + (size_t)cb * n_k * MT * 64 + lane;
+  const uint4* wfrag = reinterpret_cast<const uint4*>(w_base) + ((size_t)cb * n_k * mt_pack + msel * MT) * 64 + lane;
 
-  uint4 a_cur[MT];
+  // Weight fragments come straight from memory (L2 after the first workgroup): a ring of RING k chunks in flight per
+  // wave.  One k chunk keeps the matrix pipe busy for MT * NT * 16 (fp16) / * 128 (fp32) cycles, a fragment takes
+  // 500-800 cycles to arrive: with one chunk in flight (rounds 1-3) the small tiles - 8 x 8 stride-2 tiles, shared-out
+  // cout blocks, everything at batch 1 - waited for their weights most of the time.
+  constexpr int RING = conv_weight_ring(MT, MT * NT * (ES == 4 ? 128 : 16));
+  uint4 a_ring[RING][MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) a_cur[m] = wfrag[m * 64];
+  for (int d = 0; d < RING; ++d) {
+    const int kd = d < n_k ? d : n_k - 1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_ring[d][m] = wfrag[(size_t)(kd * mt_pack + m) * 64];
+  }
+  int phase = 0;                          // slot of the first k chunk of the current channel chunk
 
   const int slots = a.cc / EPS;              // 16-B slots per staged pixel
   const int rowslots = a.halo_w * slots;     // per halo row
@@ -185,7 +218,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       const uint32_t oyt = fdiv(p, a.div_tw);
       const uint32_t oxt = p - oyt * a.tw;
       const int py = py0 + (int)oyt, px = px0 + (int)oxt;
-      const int ch = cb * MT * 16 + slot * EPS;
+      const int ch = co_base + slot * EPS;
       rpre[it] = uint4{0u, 0u, 0u, 0u};
       if (c < NT * 16 * CHG && py < a.H_pos && px < a.W_pos && ch < a.cout_store) {
         const int oy = py * a.o_mul + oy_add, ox = px * a.o_mul + ox_add;
@@ -254,22 +287,58 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     RTPE_STAMP(3);
 
     // ---- k loop over [tap][channel] of this chunk ----
-    for (int kci = 0; kci < a.kc; ++kci, ++kf) {
-      uint4 a_nxt[MT];
-      const int kn = (kf + 1 < n_k) ? kf + 1 : kf;
+    // slot d of the ring holds k chunk kf + d at the start of a group of RING steps; a step uses its slot and refills
+    // it with the chunk RING further on
+    uint4 b_nxt[NT];
+    int off_nxt;
+    auto k_step = [&](int kci, int d) {
+      uint4 a_cur[MT];
+      const int kn = (kf + RING < n_k) ? kf + RING : n_k - 1;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a_nxt[m] = wfrag[(size_t)(kn * MT + m) * 64];
-      const int off = tapoff[kci * 4 + g];
+      for (int m = 0; m < MT; ++m) {
+        a_cur[m] = a_ring[d][m];
+        a_ring[d][m] = wfrag[(size_t)(kn * mt_pack + m) * 64];
+      }
+      // the B operands of the NEXT step are requested before this step's MFMAs, its tap offset one step earlier
+      // still (two dependent LDS round trips per step otherwise: with one wave per SIMD - small grids - nothing hid them)
       uint4 b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        b[nt] = *reinterpret_cast<const uint4*>(tile + pixbase[nt] + off);
+      for (int nt = 0; nt < NT; ++nt) {
+        b[nt] = b_nxt[nt];
+        b_nxt[nt] = *reinterpret_cast<const uint4*>(tile + pixbase[nt] + off_nxt);
+      }
+      off_nxt = tapoff[(kci + 2 < a.kc ? kci + 2 : a.kc - 1) * 4 + g];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_step<T>(a_cur[m], b[nt], acc[m][nt]);
+      ++kf;
+    };
+    {
+      const int off0 = tapoff[g];
+      off_nxt = tapoff[(a.kc > 1 ? 1 : 0) * 4 + g];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+      for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = *reinterpret_cast<const uint4*>(tile + pixbase[nt] + off0);
+    }
+    // (k chunk kf lives in slot kf % RING, a compile-time index in every step below: a channel chunk whose kc is not a
+    // multiple of RING starts in the middle of a group - `phase` - and runs head, whole groups, tail)
+    int kci = 0;
+    if constexpr (RING > 1) {
+      if (phase != 0) {
+#pragma unroll
+        for (int d = 1; d < RING; ++d)
+          if (d >= phase && kci < a.kc) { k_step(kci, d); ++kci; }
+      }
+    }
+    for (; kci + RING <= a.kc; kci += RING) {
+#pragma unroll
+      for (int d = 0; d < RING; ++d) k_step(kci + d, d);
+    }
+    if constexpr (RING > 1) {
+#pragma unroll
+      for (int d = 0; d < RING - 1; ++d)
+        if (kci + d < a.kc) k_step(kci + d, d);
+      phase = (phase + a.kc) % RING;
     }
     RTPE_STAMP(4);
 #ifdef RTPE_CONV_STAMPS
@@ -283,7 +352,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   float4v al[MT], be[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int c4 = (cb * MT + m) * 16 + g * 4;
+    const int c4 = co_base + m * 16 + g * 4;
     al[m] = *reinterpret_cast<const float4v*>(a.alpha + c4);
     be[m] = *reinterpret_cast<const float4v*>(a.beta + c4);
   }
@@ -326,7 +395,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const int py = py0 + (int)oyt, px = px0 + (int)oxt;
         if (py < a.H_pos && px < a.W_pos) {
           const int oy = py * a.o_mul + oy_add, ox = px * a.o_mul + ox_add;
-          const int c4 = (cb * MT + m) * 16 + g * 4;
+          const int c4 = co_base + m * 16 + g * 4;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int c = c4 + j;
@@ -344,7 +413,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     }
   }
   if (a.y != nullptr) {
-    const int cblk = cb * MT * 16;
+    const int cblk = co_base;
     T* yout = reinterpret_cast<T*>(a.y);
     const T* rin = reinterpret_cast<const T*>(a.res);
 #pragma unroll
@@ -517,6 +586,21 @@ bool conv_deint(const ConvPlan& p, int kind) {
   return on && kind == 0 && p.in_mul == 2 && p.dil == 1;
 }
 
+// the instantiations of conv_mfma_kernel: (cout tiles, pixel tiles per wave, waves)
+#define RTPE_CONV_VARIANTS(V)                                                                           \
+  V(3, 8, 4) V(3, 4, 4) V(3, 2, 4) V(3, 5, 4) V(3, 5, 5) V(3, 1, 4) V(4, 1, 4) V(6, 1, 4)               \
+  V(4, 4, 4) V(4, 2, 4) V(4, 5, 4) V(4, 5, 5) V(6, 2, 4)                                                \
+  V(2, 8, 4) V(2, 4, 4) V(2, 2, 4) V(2, 5, 4) V(2, 5, 5) V(2, 1, 4)                                     \
+  V(1, 8, 4) V(1, 4, 4) V(1, 2, 4) V(1, 5, 4) V(1, 5, 5) V(1, 1, 4)                                     \
+  V(6, 2, 2) V(6, 4, 1) V(4, 2, 2) V(4, 4, 1) V(3, 2, 2) V(3, 4, 1)
+
+static bool conv_has_variant(int mt, int nt, int waves) {
+#define RTPE_V(MTv, NTv, Wv) if (mt == MTv && nt == NTv && waves == Wv) return true;
+  RTPE_CONV_VARIANTS(RTPE_V)
+#undef RTPE_V
+  return false;
+}
+
 struct TileCand { int waves, nt, th, tw; };
 static const TileCand kCands[] = {
     {4, 8, 16, 32}, {4, 8, 32, 16}, {4, 4, 16, 16}, {4, 4, 8, 32}, {4, 4, 32, 8},
@@ -529,10 +613,10 @@ static const TileCand kCands[] = {
     {2, 2, 8, 8}, {1, 4, 8, 8},
 };
 
-static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt) {
+static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt, int mrun = 0) {
   const int hh = (th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   const size_t in_tile = (size_t)hh * conv_row_pitch(p, tw, 0);
-  const size_t out_tile = (size_t)waves * nt * 16 * (p.mt * 16 * p.esize + 16);   // epilogue transpose buffer
+  const size_t out_tile = (size_t)waves * nt * 16 * ((mrun ? mrun : p.mt) * 16 * p.esize + 16);   // epilogue transpose buffer
   return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
 }
 
@@ -696,6 +780,13 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool all
       best.nt = c.nt; best.waves = c.waves; best.th = c.th; best.tw = c.tw; best.lds_bytes = lds;
     }
   }
+  // RTPE_CONV_MRUN=m: untuned launches share every cout block out to mt / m workgroups where that shape exists (the
+  // autotuner times these shapes for small grids by itself: conv_enum_tiles; the switch lets a test run them everywhere)
+  static const int force_mrun = env_int("RTPE_CONV_MRUN", 0);
+  if (force_mrun > 0 && best.nt && force_mrun < p.mt && p.mt % force_mrun == 0 && conv_has_variant(force_mrun, best.nt, best.waves)) {
+    best.mrun = force_mrun;
+    best.lds_bytes = tile_lds(p, best.th, best.tw, best.waves, best.nt, force_mrun);
+  }
   return best;
 }
 
@@ -728,6 +819,7 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->div_tiles_x = make_fastdiv(a->tiles_x);
   a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
   a->n_cb = p.n_cb;
+  a->m_split = (t.kind == 0 && t.mrun > 0) ? p.mt / t.mrun : 1;
   if (a->in_cs == 0) a->in_cs = p.cc;
   if (a->out_cs == 0) a->out_cs = p.mt * 16;
   if (a->res_cs == 0) a->res_cs = p.mt * 16;
@@ -754,7 +846,8 @@ static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStr
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   const unsigned n_tiles = (unsigned)(a.N * a.tiles_x * a.tiles_y);
-  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb * (unsigned)(a.n_cls > 0 ? a.n_cls : 1));   // (tile / 8, class, cout block, tile % 8 = XCD)
+  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb * (unsigned)(a.m_split > 1 ? a.m_split : 1) *
+            (unsigned)(a.n_cls > 0 ? a.n_cls : 1));   // (tile / 8, class, cout block x share, tile % 8 = XCD)
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), t.lds_bytes, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;
@@ -765,8 +858,17 @@ static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStr
 void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector<ConvTile>* out) {
   out->clear();
   double min_waste = 1e30;
+  // a grid of fewer than 512 workgroups (batch 1; the /16 and /32 branches of small batches) leaves compute units idle
+  // while every workgroup walks the whole k chain of its 48-96 output channels: 8 x 8 pixel tiles and cout blocks
+  // shared out to several workgroups (ConvTile::mrun) are timed as well
+  auto small_grid = [&](const TileCand& c) {
+    return (long)N * p.n_cb * ((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) < 512;
+  };
+  auto tiny_ok = [&](const TileCand& c) {
+    return !(c.nt == 1 || c.waves < 4) || (p.in_mul == 2 && p.mt >= 3) || (small_grid(c) && c.waves == 4);
+  };
   for (const TileCand& c : kCands) {
-    if ((c.nt == 1 || c.waves < 4) && (p.in_mul != 2 || p.mt < 3)) continue;
+    if (!tiny_ok(c)) continue;
     const double w = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                      ((double)H_pos * W_pos);
     if (w < min_waste) min_waste = w;
@@ -774,7 +876,7 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
   for (const TileCand& c : kCands) {
     if (p.mt == 4 && c.nt == 8) continue;
     if (p.mt == 6 && c.nt > 2 && c.waves >= 4) continue;
-    if ((c.nt == 1 || c.waves < 4) && (p.in_mul != 2 || p.mt < 3)) continue;
+    if (!tiny_ok(c)) continue;
     const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
                          ((double)H_pos * W_pos);
     // (small maps - 20 x 20 at /32 - fit one 20 x 20 tile per image: 32 workgroups for 256 CUs.  Smaller tiles
@@ -785,7 +887,14 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     memset(&t, 0, sizeof(t));
     t.nt = c.nt; t.waves = c.waves; t.th = c.th; t.tw = c.tw;
     t.lds_bytes = tile_lds(p, c.th, c.tw, c.waves, c.nt);
-    if (t.lds_bytes <= 160 * 1024) out->push_back(t);              // one workgroup per tile
+    if (t.lds_bytes <= 160 * 1024 && conv_has_variant(p.mt, c.nt, c.waves)) out->push_back(t);   // one workgroup per tile
+    if (small_grid(c))
+      for (int m = p.mt / 2; m >= 1; --m) {
+        if (p.mt % m != 0 || !conv_has_variant(m, c.nt, c.waves)) continue;
+        t.mrun = m;
+        t.lds_bytes = tile_lds(p, c.th, c.tw, c.waves, c.nt, m);
+        if (t.lds_bytes <= 160 * 1024) out->push_back(t);
+      }
     static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
     if ((stream & 1) && get_option(kOptStreamPC) != 2) {
       ConvTile st;
@@ -812,9 +921,9 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
                "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
   // a launch shape belongs to one plan (halo = taps x dilation, pixel stride): never run a foreign one
-  RTPE_REQUIRE(t.kind != 0 || t.lds_bytes >= tile_lds(p, t.th, t.tw, t.waves, t.nt),
+  RTPE_REQUIRE(t.kind != 0 || t.lds_bytes >= tile_lds(p, t.th, t.tw, t.waves, t.nt, t.mrun),
                "conv tile (%zu B of LDS) was made for another plan (needs %zu B)", t.lds_bytes,
-               tile_lds(p, t.th, t.tw, t.waves, t.nt));
+               tile_lds(p, t.th, t.tw, t.waves, t.nt, t.mrun));
   RTPE_REQUIRE(a.kc * 4 * sizeof(int) <= (size_t)kTapTableBytes, "k chunk table overflow (kc=%d)", a.kc);
   const int eps = 16 / p.esize;
   RTPE_REQUIRE(a.in_ld % eps == 0 && (a.y == nullptr || (a.out_ld % eps == 0 && a.cout_store % eps == 0 &&
@@ -828,17 +937,16 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   if (t.kind == 4) return conv_direct_launch(p, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
                "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");
+  const int mrun = t.mrun > 0 ? t.mrun : p.mt;
+  RTPE_REQUIRE(p.mt % mrun == 0 && a.m_split == p.mt / mrun, "conv: %d cout tiles per workgroup do not divide the block of %d",
+               mrun, p.mt);
 #define RTPE_V(MTv, NTv, Wv)                                                                  \
-  if (p.mt == MTv && t.nt == NTv && t.waves == Wv)                                            \
+  if (mrun == MTv && t.nt == NTv && t.waves == Wv)                                            \
     return p.esize == 4 ? launch_variant<float, MTv, NTv, Wv>(t, a, p.n_cb, s)                 \
                         : launch_variant<_Float16, MTv, NTv, Wv>(t, a, p.n_cb, s);
-  RTPE_V(3, 8, 4) RTPE_V(3, 4, 4) RTPE_V(3, 2, 4) RTPE_V(3, 5, 4) RTPE_V(3, 5, 5) RTPE_V(3, 1, 4) RTPE_V(4, 1, 4) RTPE_V(6, 1, 4)
-  RTPE_V(4, 4, 4) RTPE_V(4, 2, 4) RTPE_V(4, 5, 4) RTPE_V(4, 5, 5) RTPE_V(6, 2, 4)
-  RTPE_V(2, 8, 4) RTPE_V(2, 4, 4) RTPE_V(2, 2, 4) RTPE_V(2, 5, 4) RTPE_V(2, 5, 5)
-  RTPE_V(1, 8, 4) RTPE_V(1, 4, 4) RTPE_V(1, 2, 4) RTPE_V(1, 5, 4) RTPE_V(1, 5, 5)
-  RTPE_V(6, 2, 2) RTPE_V(6, 4, 1) RTPE_V(4, 2, 2) RTPE_V(4, 4, 1) RTPE_V(3, 2, 2) RTPE_V(3, 4, 1)
+  RTPE_CONV_VARIANTS(RTPE_V)
 #undef RTPE_V
-  set_error("conv: no kernel variant mt=%d nt=%d waves=%d", p.mt, t.nt, t.waves);
+  set_error("conv: no kernel variant mt=%d nt=%d waves=%d", mrun, t.nt, t.waves);
   return RTPE_E_INVALID;
 }
 

@@ -114,7 +114,7 @@ extern "C" int rtpe_get_option(const char* name, int32_t* value) {
 }
 
 extern "C" const char* rtpe_last_error_string(void) { return g_err.c_str(); }
-extern "C" int rtpe_version(void) { return 2; }   // 2: rtpe_op_desc has lane / region, rtpe_hrnet_forward_flags
+extern "C" int rtpe_version(void) { return 3; }   // 3: 11 integers per tuned record; 2: rtpe_op_desc has lane / region, rtpe_hrnet_forward_flags
 extern "C" int rtpe_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1107,7 +1107,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     out8[7] = o.fuse == 1 ? -900001 : -900002;
     return RTPE_OK;
   }
-  out8[0] = o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
+  out8[0] = t.kind == 0 && t.mrun ? t.mrun : o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
   out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
                                                             : (int32_t)t.lds_bytes;   // pc: "/8" weight ring, "/9" resident weights
   return RTPE_OK;
@@ -1234,7 +1234,7 @@ extern "C" int rtpe_hrnet_read_record(rtpe_hrnet* h, int32_t slot, float* op_ms,
 
 // ---- tuned launch shapes: export / import (persisted by the caller, e.g. across processes) -------------------
 // One record of RTPE_TUNED_INTS int32 per (op, parity class): {nt, waves, th, tw, lds_bytes, kind, grid,
-// buf_bytes, n_bufs, n_wslots}; nt == 0 = not tuned.  Import accepts a record only if it is one of the launch
+// buf_bytes, n_bufs, n_wslots, mrun}; nt == 0 = not tuned.  Import accepts a record only if it is one of the launch
 // shapes conv_enum_tiles offers for that op at this (N, H, W) - a stale or foreign file cannot produce a launch
 // the kernels were not built for - and returns RTPE_E_INVALID without changing anything otherwise.
 extern "C" int rtpe_hrnet_tuned_ints(const rtpe_hrnet* h, int32_t* count) {
@@ -1252,7 +1252,7 @@ extern "C" int rtpe_hrnet_export_tuned(const rtpe_hrnet* h, int32_t N, int32_t H
     const ConvTile& t = it->second[i];
     int32_t* r = out + i * RTPE_TUNED_INTS;
     r[0] = t.nt; r[1] = t.waves; r[2] = t.th; r[3] = t.tw; r[4] = (int32_t)t.lds_bytes; r[5] = t.kind;
-    r[6] = t.grid; r[7] = t.buf_bytes; r[8] = t.n_bufs; r[9] = t.n_wslots;
+    r[6] = t.grid; r[7] = t.buf_bytes; r[8] = t.n_bufs; r[9] = t.n_wslots; r[10] = t.mrun;
   }
   return RTPE_OK;
 }
@@ -1279,7 +1279,7 @@ extern "C" int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int3
       bool found = false;
       for (const ConvTile& c : cands) {
         if (c.nt == r[0] && c.waves == r[1] && c.th == r[2] && c.tw == r[3] && (int32_t)c.lds_bytes == r[4] &&
-            c.kind == r[5] && c.grid == r[6] && c.buf_bytes == r[7] && c.n_bufs == r[8] && c.n_wslots == r[9]) {
+            c.kind == r[5] && c.grid == r[6] && c.buf_bytes == r[7] && c.n_bufs == r[8] && c.n_wslots == r[9] && c.mrun == r[10]) {
           tiles[i * 4 + k] = c;
           found = true;
           break;

@@ -163,6 +163,8 @@ struct ConvArgs {
                          // first, then the odd ones (n_even = number of even columns): consecutive OUTPUT pixels of a tap are
                          // then consecutive LDS pixels, as with stride 1, and the B-operand reads are bank-conflict free
   int n_even;
+  int m_split;           // one-workgroup-per-tile kernel: workgroups that share one packed cout block (ConvTile::mrun cout
+                         // tiles each); 0 / 1 = one workgroup computes the whole block
   int pc_flags;          // streaming pc kernel, diagnostic switches: 2 = the tile of the next stage is requested in two halves
                          // around the mid-stage barrier (weight ring only), 4 = plain instead of write-through row stores
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
@@ -188,6 +190,8 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
   int n_wslots;         // streaming: weight half-stage slots
+  int mrun;             // kind 0: cout tiles (x16) per workgroup, a divisor of ConvPlan::mt (0 = all mt of them): the
+                        // packed cout block is shared out to mt / mrun workgroups (small grids)
 };
 
 struct ConvGeom {       // logical layer, independent of the batch

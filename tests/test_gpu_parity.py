@@ -1736,6 +1736,56 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
 
 
+@pytest.mark.parametrize("mrun,at_least", [(1, 100), (2, 10)])
+def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun, at_least):
+    """small grids (batch 1, the /16 and /32 branches): the one-workgroup-per-tile kernel shares a packed block of 48 /
+    64 / 96 output channels out to several workgroups of ``mrun`` 16-channel tiles each (ConvTile::mrun,
+    csrc/conv_mfma.hip) - the autotuner times these shapes when fewer than 512 workgroups would run.  A second process
+    runs EVERY conv that way (RTPE_CONV_MRUN, untuned launches, no streaming / fused / direct kernels) - half wrapper and
+    fp32 network - and must give the bits this process computes with its tuned product configuration"""
+    import subprocess
+    import sys
+    from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
+    m16, sd = teacher("W1")
+    m32 = PoseHigherResolutionNet()
+    m32.load_state_dict(sd, strict=True)
+    m32 = m32.to("cuda:0").eval()
+    x = synth.make_images(1, 160, 224, seed=91).to("cuda:0")
+    with torch.no_grad():
+        p16, r16 = m16(x)
+        p32, r32 = m32(x)
+    out = str(tmp_path / "mrun.npz")
+    code = (
+        "import sys, json, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from oracle import synth\n"
+        "from rtpe.helpers import build_hrnet_w48_teacher\n"
+        "from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet\n"
+        "shapes = {k: tuple(v) for k, v in json.load(open(%r))['shapes'].items()}\n"
+        "sd = synth.make_state_dict(shapes, 0, 'W1')\n"
+        "m16 = build_hrnet_w48_teacher({'1.' + k: v for k, v in sd.items()}).to('cuda:0')\n"
+        "m32 = PoseHigherResolutionNet()\n"
+        "m32.load_state_dict(sd, strict=True)\n"
+        "m32 = m32.to('cuda:0').eval()\n"
+        "x = synth.make_images(1, 160, 224, seed=91).to('cuda:0')\n"
+        "with torch.no_grad():\n"
+        "    p16, r16 = m16(x)\n"
+        "    p32, r32 = m32(x)\n"
+        "for eng in (next(iter(m16[1]._engines.values())), next(iter(m32._engines.values()))):\n"
+        "    tiles = [eng.op_tile(i, 1, 160, 224) for i in range(len(eng.program.ops))]\n"
+        "    shared = sum(1 for t in tiles if t[0] == %d and t[7] > 0)\n"
+        "    assert shared >= %d, shared\n"
+        "np.savez(%r, p16=p16.cpu().numpy(), r16=r16.cpu().numpy(), p32=p32.cpu().numpy(), r32=r32.cpu().numpy())\n"
+    ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
+         os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
+    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
+               RTPE_PAIR_1X1="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
+    ref = np.load(out)
+    for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
+        assert np.array_equal(ref[name], t.cpu().numpy()), name
+
+
 def test_1x1_pairs_do_not_change_the_network_output(nat, teacher):
     """conv3 + bn3 + residual + ReLU of a layer1 Bottleneck and conv1 + bn1 + ReLU of the next one (reference :96-116) run
     as ONE kernel that never reads the 256-channel tensor back (option "pair_1x1", csrc/conv_pair.hip): the program flags
