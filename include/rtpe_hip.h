@@ -267,7 +267,10 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * other work of the process runs on a HIGH-priority stream the lanes more than halve the throughput; use 0 there.  "tile_dma" (env RTPE_TILE_DMA): the one-workgroup-per-tile conv kernel stages its halo tiles 1 = by LDS-DMA (one
  * memory round trip per channel chunk, no staging registers; default), 0 = through registers, eight 16-byte loads per lane at a
  * time.  "pair_1x1" (env RTPE_PAIR_1X1): op pairs flagged RTPE_F_PAIR_HEAD / _TAIL run 1 = as one kernel (csrc/conv_pair.hip;
- * default), 0 = as two launches. */
+ * default), 0 = as two launches.  "fused_stem" (env RTPE_FUSED_STEM): the stem op (conv1 + bn1 + relu) and the 64 -> 64
+ * stride-2 conv behind it (conv2 + bn2 + relu) of a half-precision program run 1 = as one kernel that keeps the
+ * half-resolution map in LDS (csrc/stem_fused.hip; default), 0 = as two launches, 2 = as two launches with the stem op on
+ * the fused kernel's conv1 code (its multiply-add chain on the matrix pipe; a test setting).  Same bits in all three. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */
@@ -305,7 +308,8 @@ int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, cons
  * v > 0: LDS bytes of the one-workgroup-per-tile kernel; v <= -100000:
  * -(workgroups + 100000 * halo buffers) of the streaming kernel; -900001 / -900002: first /
  * second conv of a BasicBlock that runs as ONE fused kernel (conv_block.hip), launched by the
- * first */
+ * first; -600001 / -600002: the stem op / the 64 -> 64 stride-2 conv behind it when both run as
+ * one kernel (stem_fused.hip, option "fused_stem"), launched at the stem op */
 int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8);
 
 /* ------------------------------------------------------------------------ *

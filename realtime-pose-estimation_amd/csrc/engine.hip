@@ -38,6 +38,7 @@ struct OpState {
   int n_geom;
   int fuse;             // 1: head of a fused BasicBlock (this conv + the next run as one kernel), 2: its second conv
   int pair;             // 1: head of a 1x1 pair (conv_pair.hip: launched with the next op), 2: its tail
+  int stem2;            // 1: the stem op whose conv1 runs together with the next op's conv2 (stem_fused.hip), 2: that conv op
 };
 
 }  // namespace rtpe
@@ -78,9 +79,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
 static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", ""};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", ""};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 0};
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -224,6 +225,30 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     if (other_reader) continue;
     a1.fuse = 1;
     a2.fuse = 2;
+  }
+  // fused stem (stem_fused.hip): the stem op, then conv 64->64 k3 s2 (+relu) that is the only reader of its output
+  for (OpState& o : h->ops) o.stem2 = 0;
+  for (size_t i = 0; i + 1 < h->ops.size(); ++i) {
+    OpState& a1 = h->ops[i];
+    OpState& a2 = h->ops[i + 1];
+    const rtpe_op_desc &d1 = a1.d, &d2 = a2.d;
+    if (d1.kind != RTPE_OP_STEM || (d1.flags & RTPE_F_F32) || d2.kind != RTPE_OP_CONV || a2.fuse || a2.n_geom != 1) continue;
+    const ConvPlan& p2 = a2.plan[0];
+    if (d2.cin != 64 || d2.cout != 64 || d2.ksize != 3 || d2.stride != 2 || d2.res_t >= 0 || d2.n_terms != 0 ||
+        (d2.flags & ~(RTPE_F_RELU | RTPE_F_ROUND_CONV)) || d2.in_t != d1.out_t || d2.in_coff != 0 || d1.out_coff != 0 ||
+        d2.reserved[1] > 1 || d2.reserved[2] > 0 || d2.out_t == d1.out_t || h->tensors[d1.out_t].channels != 64 ||
+        h->tensors[d2.out_t].channels - d2.out_coff < 64 || d1.lane != d2.lane || d1.region != d2.region ||
+        p2.mt != 4 || p2.cc != 64 || p2.n_cchunks != 1 || p2.kc != 18 || p2.n_cb != 1 || p2.esize != 2)
+      continue;
+    bool other_reader = false;
+    for (size_t k = i + 2; k < h->ops.size() && !other_reader; ++k) {
+      const rtpe_op_desc& dk = h->ops[k].d;
+      if (dk.in_t == d1.out_t || dk.res_t == d1.out_t) other_reader = true;
+      for (int t = 0; t < dk.n_terms; ++t) other_reader |= dk.term_t[t] == d1.out_t;
+    }
+    if (other_reader) continue;
+    a1.stem2 = 1;
+    a2.stem2 = 2;
   }
   // 1x1 pairs (conv_pair.hip): the flags are the program's promise that the head's input and residual stay alive over the
   // tail; whether the two ops ARE such a pair is checked here (anything else: the flags are ignored)
@@ -561,7 +586,40 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           for (int j : h->wait_ops[i + 1]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
       }
     }
-    if (d.kind == RTPE_OP_STEM) {
+    const bool stem_fused_on = force == nullptr && only_op < 0 && get_option(kOptFusedStem) == 1 && stem_fused_supports(H, W);
+    if (d.kind == RTPE_OP_STEM && o.stem2 == 1 && stem_fused_on) {
+      // conv1 + bn1 + relu + conv2 + bn2 + relu in one kernel: the half-resolution map stays in LDS (stem_fused.hip)
+      const OpState& o2 = h->ops[i + 1];
+      const rtpe_op_desc& d2 = o2.d;
+      StemFusedArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = x; a.x_f32 = x_dtype == RTPE_DTYPE_F32;
+      a.w1 = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[0]);
+      a.alpha1 = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
+      a.beta1 = a.alpha1 + 64;
+      a.w2 = reinterpret_cast<const _Float16*>(h->arena + o2.w_dev_off[0]);
+      a.alpha2 = reinterpret_cast<const float*>(h->arena + o2.ab_dev_off);
+      a.beta2 = a.alpha2 + o2.plan[0].cout_pad;
+      a.y = tptr(d2.out_t, d2.out_coff);
+      a.N = N; a.H = H; a.W = W; a.out_ld = h->tensors[d2.out_t].channels;
+      a.relu = (d2.flags & RTPE_F_RELU) ? 1 : 0;
+      a.round_conv = (d2.flags & RTPE_F_ROUND_CONV) ? 1 : 0;
+      RTPE_HP_LAUNCH(rc = stem_fused_launch(a, s));
+    } else if (d.kind == RTPE_OP_CONV && o.stem2 == 2 && stem_fused_on) {
+      // done by the launch at the stem op
+    } else if (d.kind == RTPE_OP_STEM && !(d.flags & RTPE_F_F32) && get_option(kOptFusedStem) == 2 && stem_fused_supports(H, W)) {
+      // option "fused_stem" = 2: the stem op alone on the fused kernel's conv1 code (the chain on the matrix pipe),
+      // output to memory - the bit-identity test of that chain against the VALU kernel
+      StemFusedArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = x; a.x_f32 = x_dtype == RTPE_DTYPE_F32;
+      a.w1 = reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[0]);
+      a.alpha1 = reinterpret_cast<const float*>(h->arena + o.ab_dev_off);
+      a.beta1 = a.alpha1 + 64;
+      a.y1 = tptr(d.out_t, d.out_coff);
+      a.N = N; a.H = H; a.W = W; a.out_ld = h->tensors[d.out_t].channels;
+      RTPE_HP_LAUNCH(rc = stem_fused_launch(a, s));
+    } else if (d.kind == RTPE_OP_STEM) {
       const rtpe_tensor_desc& to = h->tensors[d.out_t];
       StemArgs a;
       a.x = x; a.x_f32 = x_dtype == RTPE_DTYPE_F32;
@@ -1086,6 +1144,11 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
   RTPE_REQUIRE(h && out8 && op >= 0 && op < (int)h->ops.size(), "op_tile: bad argument");
   const OpState& o = h->ops[op];
   memset(out8, 0, 8 * sizeof(int32_t));
+  if (o.stem2 && get_option(kOptFusedStem) == 1 && stem_fused_supports(H, W)) {   // fused stem (stem_fused.hip): 8 x 16 tiles, 8 waves
+    out8[0] = 4; out8[1] = 4; out8[2] = 8; out8[3] = 8; out8[4] = 16; out8[5] = 64; out8[6] = 1;
+    out8[7] = o.stem2 == 1 ? -600001 : -600002;
+    return RTPE_OK;
+  }
   if (o.n_geom == 0) return RTPE_OK;
   const rtpe_op_desc& d = o.d;
   const rtpe_tensor_desc& ti = h->tensors[d.in_t];

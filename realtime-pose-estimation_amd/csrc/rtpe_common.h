@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kNumOptions = 8 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kOptFusedStem = 7, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -259,6 +259,26 @@ struct StemArgs {
   int f32;      // 1: fp32 weights / output, no intermediate rounding
 };
 int stem_launch(const StemArgs& a, hipStream_t s);
+
+// the stem of a half-precision program on the matrix cores (stem_fused.hip): conv1 + bn1 + relu alone (y1 set), or with
+// conv2 + bn2 + relu behind it as one kernel (y1 null; y, w2, alpha2, beta2 set)
+struct StemFusedArgs {
+  const void* x;          // NCHW (N,3,H,W), fp32 or fp16
+  int x_f32;
+  const _Float16* w1;     // [27][64] fp16, k = (ky*3+kx)*3 + c (the stem op's weights)
+  const float* alpha1;
+  const float* beta1;
+  const _Float16* w2;     // the conv op's packed fragments (plan: mt 4, one 64-channel chunk, 18 k steps, one cout block)
+  const float* alpha2;
+  const float* beta2;
+  _Float16* y;            // fused: NHWC (N,H/4,W/4,out_ld >= 64)
+  _Float16* y1;           // conv1 only: NHWC (N,H/2,W/2,out_ld >= 64)
+  int N, H, W, out_ld;
+  int relu, round_conv;   // of the conv op
+  int ablate;             // profiling: 1 skip conv1's FMAs, 2 skip conv2's k loop, 4 skip the patch prefetch, 8 skip the stores
+};
+bool stem_fused_supports(int H, int W);
+int stem_fused_launch(const StemFusedArgs& a, hipStream_t s);
 
 // ---- student ops (student_ops.hip), fp32 NHWC ------------------------------
 int cast_launch(const _Float16* x, int in_ld, float* y, int out_ld, int C, size_t pixels, hipStream_t s);

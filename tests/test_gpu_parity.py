@@ -1730,7 +1730,8 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
         "np.savez(%r, p=p.cpu().numpy(), r=r.cpu().numpy())\n"
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
-    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0")
+    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0",
+               RTPE_FUSED_STEM="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
@@ -1779,11 +1780,46 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
-               RTPE_PAIR_1X1="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
         assert np.array_equal(ref[name], t.cpu().numpy()), name
+
+
+def test_fused_stem_does_not_change_the_network_output(nat, teacher):
+    """conv1 + bn1 + relu and conv2 + bn2 + relu of the stem (reference pose_higher_hrnet.py:363-368 / :638-643) run as ONE
+    kernel that keeps the half-resolution 64-channel map in LDS (option "fused_stem", csrc/stem_fused.hip): the program
+    has one such pair, and the network's outputs are the bits of the two-launch path - widths whose /4 map is not a
+    multiple of the 16-pixel tile, a single tile, odd batch sizes, fp16 input, repeated"""
+    L = nat.lib()
+    m, sd = teacher("W1")
+    eng = m[1]._engine(torch.device("cuda:0"))
+    try:
+        for n, hw, half_in in ((1, (64, 96), False), (3, (160, 224), False), (2, (96, 32), True), (5, (128, 352), False),
+                               (2, (640, 640), False)):
+            x = synth.make_images(n, hw[0], hw[1], seed=60 + n).to("cuda:0")
+            if half_in:
+                x = x.half()
+            nat.check(L.rtpe_set_option(b"fused_stem", 0))
+            kinds0 = [eng.op_tile(i, n, hw[0], hw[1])[7] for i in range(len(eng.program.ops))]
+            with torch.no_grad():
+                p0, r0 = m(x)
+            nat.check(L.rtpe_set_option(b"fused_stem", 1))
+            kinds1 = [eng.op_tile(i, n, hw[0], hw[1])[7] for i in range(len(eng.program.ops))]
+            assert -600001 not in kinds0 and kinds1.count(-600001) == 1 and kinds1.count(-600002) == 1
+            for rep in range(2):
+                with torch.no_grad():
+                    p1, r1 = m(x)
+                assert torch.equal(p0, p1) and torch.equal(r0, r1), (n, hw, rep)
+            # 2: the stem op alone on the fused kernel's conv1 code (7 chained k = 4 fp32 MFMAs per output instead of 27
+            # vector FMAs), then the plain conv kernel
+            nat.check(L.rtpe_set_option(b"fused_stem", 2))
+            with torch.no_grad():
+                p2, r2 = m(x)
+            assert torch.equal(p0, p2) and torch.equal(r0, r2), (n, hw, "conv1 only")
+    finally:
+        nat.check(L.rtpe_set_option(b"fused_stem", 1))
 
 
 def test_1x1_pairs_do_not_change_the_network_output(nat, teacher):

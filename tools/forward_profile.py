@@ -55,6 +55,7 @@ def main():
         tag = ""
         if t[0]:
             kind = (" PAIR-HEAD (launched with the next op)" if t[7] == -800001 else " PAIR (both 1x1 convs)" if t[7] == -800002 else
+                    " FUSED-STEM" if t[7] in (-600001, -600002) else
                     " S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else ""
             tag = " [m%d n%d w%d %dx%d cc%d cb%d%s]" % (tuple(t[:7]) + (kind,))
         key = "%s @/%d%s" % (nm, 1 << ds, tag)
@@ -69,6 +70,17 @@ def main():
             d[1] += acc[i] + pair_head[0]
             d[2] += c[0] + pair_head[1]
             d[3] += c[1] + pair_head[2]
+            continue
+        if t[0] and t[7] == -600001:                      # stem + the conv behind it as one kernel, launched here
+            stem_head = (acc[i], c[0])
+            continue
+        if t[0] and t[7] == -600002:
+            key = "stem 3->64 k3s2 + conv 64->64 k3s2+relu @/%d [one kernel: 8 waves, 8x16 tiles, conv1 region in LDS]" % (1 << ds)
+            d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += acc[i] + stem_head[0]
+            d[2] += c[0] + stem_head[1]
+            d[3] += B * 3 * S * S * 4 + B * (S // 4) * (S // 4) * 64 * 2      # fp32 image in, /4 map out
             continue
         if t[0] and t[7] == -900002:                      # second conv of a fused BasicBlock: its work belongs to the
             d = by[head_key]                              # launch of the first (time 0 here)
