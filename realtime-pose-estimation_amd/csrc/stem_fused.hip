@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(kThreads) stem_fused_kernel(const StemFusedArg
   if (tid < 128) ab1[tid] = tid < 64 ? a.alpha1[tid] : a.beta1[tid - 64];
   // this lane's pixel in each of the wave's conv1 pixel tiles (pixel tile wv + 8 i, pixel p = 16 * tile + r)
   int pixoff[kTilesPerWave];    // patch element offset of the pixel's top-left tap
-  int c1off[kTilesPerWave];     // byte offset of the lane's first 8 bytes in the conv1 tile; -1: no such pixel
+  int c1off[kTilesPerWave];     // byte offset of the lane's first 8 bytes in the conv1 tile; a pixel beyond the region
+                                // (15 lanes of the last pixel tile) writes into the idle transpose buffer instead: no
+                                // branch in the epilogue, which the scheduler interleaves with the next tile's MFMAs
   int cyx[kTilesPerWave];       // cy | cx << 8
 #pragma unroll
   for (int i = 0; i < kTilesPerWave; ++i) {
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(kThreads) stem_fused_kernel(const StemFusedArg
     const int pc = p < kC1Px ? p : kC1Px - 1;
     const int cy = pc / kC1W, cx = pc - cy * kC1W;
     pixoff[i] = 2 * cy * kPWp + 2 * cx;
-    c1off[i] = p < kC1Px ? cy * kRowB + ((cx & 1) * kNEven + (cx >> 1)) * kPS + g * 8 : -1;
+    c1off[i] = p < kC1Px ? cy * kRowB + ((cx & 1) * kNEven + (cx >> 1)) * kPS + g * 8 : kC1Bytes + lane * 128;
     cyx[i] = cy | (cx << 8);
   }
   float4v al2 = float4v{0.f, 0.f, 0.f, 0.f}, be2 = al2;
@@ -175,9 +177,10 @@ __global__ void __launch_bounds__(kThreads) stem_fused_kernel(const StemFusedArg
     if (t + wg_per_xcd < t_end && !(a.ablate & 4)) load_patch(t + wg_per_xcd);
 
     // ---- conv1 + bn1 + relu -> LDS: 7 chained k = 4 MFMAs per (16 pixels, 16 channels) ----
-    // Software-pipelined inside the wave: the chains of pixel tile i (an MFMA every 32 cycles) leave the
-    // vector ALU idle - the BatchNorm / rounding / ReLU of pixel tile i - 1 goes into those slots (one after the other
-    // the two cost 7.8k + 4.8k cycles per tile and SIMD).
+    // Software-pipelined inside the wave: the BatchNorm / rounding / ReLU of pixel tile i - 1 is scheduled between the
+    // MFMAs of pixel tile i (one MFMA, five vector instructions).  Measured at batch 32: chains alone 88 us (the matrix
+    // pipe's fp32 rate), epilogue alone 54 us, together 142-170 us - with two waves per SIMD both in the same phase the
+    // two do not overlap, interleaved or not (profiles/r04_stem_fused_ablation.txt); kept because it costs nothing.
     if (!(a.ablate & 1)) {
       const int c1y0 = 2 * oy0 - 1, c1x0 = 2 * ox0 - 1;
       struct Acc4 { float4v t[4]; };
@@ -207,13 +210,13 @@ __global__ void __launch_bounds__(kThreads) stem_fused_kernel(const StemFusedArg
           for (int j = 0; j < 4; ++j) {
             float x = round16(acc.t[mm][j]);                               // conv output
             x = __builtin_fmaf(x, al[j], be[j]);                           // BN output
-            asm volatile("" : "+v"(x));                                    // (kept apart from the cast: stem_kernel rounds twice)
+            asm("" : "+v"(x));                                             // (kept apart from the cast: stem_kernel rounds twice; not volatile: free to move)
             x = round16(x);
             o[j] = (_Float16)((inside && x > 0.f) ? x : 0.f);
           }
           unsigned long long raw;
           __builtin_memcpy(&raw, o, 8);
-          if (c1off[i] >= 0) *reinterpret_cast<unsigned long long*>(c1 + c1off[i] + mm * 32) = raw;
+          *reinterpret_cast<unsigned long long*>(c1 + c1off[i] + mm * 32) = raw;
         }
       };
       auto interleave = [&]() {            // one MFMA, then vector work, 28 times
