@@ -332,7 +332,12 @@ int stem_fused_launch(const StemFusedArgs& a, hipStream_t s) {
   const int Ho2 = a.H / 4, Wo2 = a.W / 4;
   const long tiles = (long)a.N * ((Wo2 + kT2W - 1) / kT2W) * ((Ho2 + kT2H - 1) / kT2H);
   const long per_xcd = (tiles + 7) / 8;
-  const long g = per_xcd < 32 ? per_xcd : 32;                      // one workgroup per CU
+  // workgroups per XCD: 32 = one per CU, each with 1/256 of the tiles.  RTPE_STEM_WGS (default 1) times as many, each
+  // with fewer tiles: a CU that is busy with another stream's kernels (the decode of the previous batch runs beside the
+  // start of a forward) then takes fewer of them
+  static const int wgs = env_int("RTPE_STEM_WGS", 1);
+  const long cap = 32L * (wgs > 0 ? wgs : 1);
+  const long g = per_xcd < cap ? per_xcd : cap;
   StemFusedArgs b = a;
   static const int abl = RTPE_DIAG_ENV_INT("RTPE_STEM_ABL", 0);
   b.ablate = abl;

@@ -3,7 +3,7 @@
     python tools/trace_summary.py [--last-forwards K] [--csv out.csv] trace.csv ...
 
 --last-forwards K keeps only the dispatches from the start of the K-th last forward pass on
-(one stem_kernel launch per forward), i.e. the timed steps of bench.py without warm-up and
+(one stem_kernel / stem_fused_kernel launch per forward), i.e. the timed steps of bench.py without warm-up and
 autotuning passes.
 """
 import argparse
@@ -36,7 +36,7 @@ def main():
             rows = list(csv.DictReader(open(path)))
             rows.sort(key=lambda r: int(r["Start_Timestamp"]))
             if a.last_forwards:
-                stems = [int(r["Start_Timestamp"]) for r in rows if "stem_kernel" in r["Kernel_Name"]]
+                stems = [int(r["Start_Timestamp"]) for r in rows if "stem_kernel" in r["Kernel_Name"] or "stem_fused_kernel" in r["Kernel_Name"]]
                 if len(stems) >= a.last_forwards:
                     t0 = stems[-a.last_forwards]
                     t1 = stems[-a.drop_last] if a.drop_last else None
