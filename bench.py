@@ -50,9 +50,12 @@ def parse_args():
                                                "coco_minival2017_100.txt); a step = one pass over the whole list, "
                                                "sharded contiguously over the ranks, uneven shards, short last batches, "
                                                "all-gather of the keypoint records with counts")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
+    import glob
+    summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+    ap.add_argument("--pmc-json", default=summaries[-1] if summaries else os.path.join(ROOT, "profiles", "pmc_summary.json"),
                     help="per-kernel PMC summary written by tools/pmc_summary.py from rocprofv3 --pmc passes of THIS "
-                         "command; roofline.traffic is read from it when it was made from the same kernel sources")
+                         "command (default: the latest profiles/rNN_pmc_summary.json); roofline.traffic is read from it "
+                         "when it was made from the same kernel sources")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
                     help="BASELINE.json configs[]: 2 (default) = batch 32 fp16 teacher forward + decode, the headline; "
                          "1 = batch 1 fp32 teacher forward + decode (latency form of the same metric); 4 = the "

@@ -53,7 +53,7 @@ def load(path, keep_forwards=6, drop_last=3, raw_out=None):
                                       "t1": int(r["End_Timestamp"]), "c": {}})
         d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     disp = sorted(per_disp.values(), key=lambda d: d["t0"])
-    stems = [i for i, d in enumerate(disp) if d["name"].startswith("stem_kernel")]
+    stems = [i for i, d in enumerate(disp) if d["name"].startswith(("stem_kernel", "stem_fused_kernel"))]
     if len(stems) >= keep_forwards + drop_last:
         a = stems[-(keep_forwards + drop_last)]
         b = stems[-drop_last] if drop_last else len(disp)
@@ -61,7 +61,7 @@ def load(path, keep_forwards=6, drop_last=3, raw_out=None):
     out = collections.OrderedDict()
     nth = 0
     for d in disp:
-        if d["name"].startswith("stem_kernel"):
+        if d["name"].startswith(("stem_kernel", "stem_fused_kernel")):
             nth = 0
         cls = d["grid"]
         if d["name"].startswith("conv_block"):
