@@ -251,6 +251,70 @@ def test_stem_and_nchw_head_epilogues(nat, hw, n, f32in):
         assert err.max() <= 2.0 and same > 0.97
 
 
+@pytest.mark.parametrize("hw,n,f32in", [((64, 96), 2, True), ((160, 224), 3, True), ((32, 32), 1, False), ((96, 352), 5, True),
+                                        ((256, 256), 9, True)])
+def test_fused_stem_layer_level(nat, hw, n, f32in):
+    """layer-level check of the fused stem kernel (csrc/stem_fused.hip) through the ABI: a four-op program - stem, the
+    64 -> 64 stride-2 conv behind it, two 1x1 heads that write NCHW fp32 - against the fp16 PyTorch-CPU ops of the
+    reference's stem (pose_higher_hrnet.py:363-368: conv1, bn1, relu, conv2, bn2, relu with one rounding after conv, BN
+    and ReLU), and bit for bit against the same program with the option off (two launches).  Sizes with partial tiles on
+    both axes, a single tile, more tiles than workgroups (9 x 256 x 256: 288 tiles for 256 persistent workgroups)"""
+    import torch.nn as nn
+    from rtpe.third_party.pose_higher_hrnet import Engine, ProgramBuilder
+    H, W = hw
+    L = nat.lib()
+    g = torch.Generator().manual_seed(H * 11 + W)
+    conv1, bn1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+    conv2, bn2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+    heads = [nn.Conv2d(64, 34, 1, bias=True), nn.Conv2d(64, 17, 1, bias=True)]
+    with torch.no_grad():
+        conv1.weight.copy_((torch.rand(conv1.weight.shape, generator=g) * 2 - 1) / 27 ** 0.5)
+        conv2.weight.copy_((torch.rand(conv2.weight.shape, generator=g) * 2 - 1) / 576 ** 0.5 * 2.0)
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.rand(64, generator=g) * 0.4 + 0.8)
+            bn.bias.copy_(torch.randn(64, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(64, generator=g) * 0.05)
+            bn.running_var.copy_(torch.rand(64, generator=g) * 0.2 + 0.9)
+        for hd in heads:
+            hd.weight.copy_((torch.rand(hd.weight.shape, generator=g) * 2 - 1) / 8.0)
+            hd.bias.copy_(torch.randn(hd.out_channels, generator=g) * 0.1)
+    for mod in [conv1, conv2] + heads:
+        mod.half()
+    b = ProgramBuilder(f32=False)
+    t = b.stem(conv1, bn1)
+    t = b.conv(t, conv2, bn2, relu=True)
+    b.conv(t, heads[0], None, out_flag=nat.F_OUT_PREDS, nhwc=False)
+    b.conv(t, heads[1], None, out_flag=nat.F_OUT_REFINED, nhwc=False)
+    eng = Engine(b.finish(), 0)
+    x = torch.randn(n, 3, H, W, generator=g)
+    xin = (x if f32in else x.half()).to("cuda:0")
+    try:
+        with torch.no_grad():
+            nat.check(L.rtpe_set_option(b"fused_stem", 1))
+            assert eng.op_tile(0, n, H, W)[7] == -600001 and eng.op_tile(1, n, H, W)[7] == -600002
+            preds, refined = eng.forward(xin, torch.float32)
+            nat.check(L.rtpe_set_option(b"fused_stem", 0))
+            assert eng.op_tile(0, n, H, W)[7] != -600001
+            p0, r0 = eng.forward(xin, torch.float32)
+            assert torch.equal(p0, preds) and torch.equal(r0, refined)
+            y = F.conv2d(x.half(), conv1.weight, None, 2, 1)
+            y = F.relu(bn1.float().eval()(y.float()).half())
+            y = F.conv2d(y, conv2.weight, None, 2, 1)
+            y = F.relu(bn2.float().eval()(y.float()).half())
+            want = [F.conv2d(y, hd.weight, hd.bias).float() for hd in heads]
+    finally:
+        nat.check(L.rtpe_set_option(b"fused_stem", 1))
+    assert preds.shape == (n, 34, H // 4, W // 4) and refined.shape == (n, 17, H // 4, W // 4)
+    for name, got, w_ in (("head 34", preds, want[0]), ("head 17", refined, want[1])):
+        gotn, wn = got.cpu().numpy(), w_.numpy()
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(wn), 0.25))) - 10)
+        err = np.abs(gotn - wn) / ulp
+        same = (gotn == wn).mean()
+        print("fused stem %dx%d n=%d %s: max %.2f fp16 steps, identical %.4f" % (H, W, n, name, err.max(), same))
+        # (one more conv + BN + ReLU of roundings between the input and the heads than in the stem-only test above)
+        assert err.max() <= 2.0 and same > 0.97
+
+
 STREAM_CASES = [
     # cin, cout, H, W, N, residual: enough (tile, cout block) units that every persistent workgroup of the
     # streaming kernel walks several of them (halo buffer ring, weight ring, residual sets two units ahead)
