@@ -270,7 +270,10 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * default), 0 = as two launches.  "fused_stem" (env RTPE_FUSED_STEM): the stem op (conv1 + bn1 + relu) and the 64 -> 64
  * stride-2 conv behind it (conv2 + bn2 + relu) of a half-precision program run 1 = as one kernel that keeps the
  * half-resolution map in LDS (csrc/stem_fused.hip; default), 0 = as two launches, 2 = as two launches with the stem op on
- * the fused kernel's conv1 code (its multiply-add chain on the matrix pipe; a test setting).  Same bits in all three. */
+ * the fused kernel's conv1 code (its multiply-add chain on the matrix pipe; a test setting).  Same bits in all three.
+ * "conv64" (env RTPE_CONV64): the 3x3 stride-1 convs with 64 input and 64 output channels and no residual (conv2 of layer1's
+ * Bottlenecks) run 1 = on persistent workgroups with double-buffered halo tiles and register-resident weights
+ * (csrc/conv64.hip; default, and one more launch shape for the autotuner), 0 = on the one-workgroup-per-tile kernel. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */
@@ -308,7 +311,7 @@ int rtpe_hrnet_import_tuned(rtpe_hrnet* h, int32_t N, int32_t H, int32_t W, cons
  * v > 0: LDS bytes of the one-workgroup-per-tile kernel; v <= -100000:
  * -(workgroups + 100000 * halo buffers) of the streaming kernel; -900001 / -900002: first /
  * second conv of a BasicBlock that runs as ONE fused kernel (conv_block.hip), launched by the
- * first; -600001 / -600002: the stem op / the 64 -> 64 stride-2 conv behind it when both run as
+ * first; -(500000 + workgroups): the persistent 64 -> 64 3x3 kernel (conv64.hip); -600001 / -600002: the stem op / the 64 -> 64 stride-2 conv behind it when both run as
  * one kernel (stem_fused.hip, option "fused_stem"), launched at the stem op */
 int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, int32_t W, int32_t* out8);
 

@@ -763,10 +763,23 @@ static bool direct_tile(const ConvPlan& p, ConvTile* out) {
   return true;
 }
 
-ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct) {
+static bool conv64_tile(const ConvPlan& p, int N, int H_pos, int W_pos, ConvTile* out) {
+  if (!conv64_supports(p) || get_option(kOptConv64) == 0) return false;
+  memset(out, 0, sizeof(*out));
+  out->kind = 5; out->nt = 2; out->waves = 8; out->th = 16; out->tw = 16;      // 16 x 16 = 16 x 2 x 8: the common check
+  out->grid = conv64_grid(N, H_pos, W_pos);
+  out->lds_bytes = conv64_lds();
+  return true;
+}
+
+ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct, bool allow_conv64) {
   if (allow_direct) {
     ConvTile t;
     if (direct_tile(p, &t)) return t;
+  }
+  if (allow_conv64) {
+    ConvTile t;
+    if (conv64_tile(p, N, H_pos, W_pos, &t)) return t;
   }
   if (get_option(kOptStreamPC) == 2 && conv_stream_pc_supports(p)) {
     ConvTile t = make_stream_pc_tile(p, N, H_pos, W_pos);
@@ -940,6 +953,7 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
   {
     ConvTile dt;
     if (direct_tile(p, &dt)) out->push_back(dt);                 // 1x1: no staged tile at all (conv_direct.hip)
+    if (conv64_tile(p, N, H_pos, W_pos, &dt)) out->push_back(dt);   // 64 -> 64 3x3: persistent, pipelined (conv64.hip)
   }
 }
 
@@ -962,6 +976,7 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   if (t.kind == 2) return conv_stream_launch(p, t, a, s);
   if (t.kind == 3) return conv_stream_pc_launch(p, t, a, s);
   if (t.kind == 4) return conv_direct_launch(p, a, s);
+  if (t.kind == 5) return conv64_launch(p, t, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
                "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");
   const int mrun = t.mrun > 0 ? t.mrun : p.mt;

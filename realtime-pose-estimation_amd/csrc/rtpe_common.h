@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kOptFusedStem = 7, kNumOptions = 8 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kOptFusedStem = 7, kOptConv64 = 8, kNumOptions = 9 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -185,7 +185,8 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int th, tw;
   size_t lds_bytes;
   int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
-                        // (conv_stream.hip), 3: streaming, producer / consumer wave groups (conv_stream_pc.hip), 4: direct 1x1 (conv_direct.hip)
+                        // (conv_stream.hip), 3: streaming, producer / consumer wave groups (conv_stream_pc.hip), 4: direct 1x1
+                        // (conv_direct.hip), 5: 64 -> 64 3x3 on persistent workgroups (conv64.hip)
   int grid;             // streaming: number of workgroups
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
@@ -204,7 +205,8 @@ struct ConvGeom {       // logical layer, independent of the batch
 ConvPlan conv_make_plan(const ConvGeom& g);
 // choose the tile for a position grid (N images of H_pos x W_pos positions)
 // (allow_direct = false: never the direct 1x1 kernel, whose launch needs a < 2 GiB input view and a plain NHWC output)
-ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct = true);
+// (allow_conv64 = false: never the persistent 64 -> 64 kernel, which takes no residual and writes plain NHWC rows)
+ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct = true, bool allow_conv64 = true);
 // LDS bytes per row of the staged input tile of a tw-wide output tile: halo_w * pstride, padded (fp16) so that a
 // 16-pixel MFMA column tile which wraps to the next output row keeps the bank pattern of consecutive pixels
 int conv_row_pitch(const ConvPlan& p, int tw, int kind);
@@ -229,6 +231,12 @@ int conv_stream_pc_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& 
 bool conv_pair_supports(int cin1, int cout1, int cout2);
 int conv_pair_launch(const ConvPlan& p1, const ConvArgs& c1, const ConvPlan& p2, const ConvArgs& c2, hipStream_t s);
 int conv_direct_mb(const ConvPlan& p);
+// 3x3 stride-1 64 -> 64 convs without residual on persistent workgroups with double-buffered LDS-DMA halo tiles and
+// register-resident weights (conv64.hip, ConvTile::kind == 5: 16 x 16 tiles, 8 waves)
+bool conv64_supports(const ConvPlan& p);
+size_t conv64_lds();
+int conv64_grid(int N, int H_pos, int W_pos);
+int conv64_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);

@@ -202,6 +202,56 @@ def test_producer_consumer_streaming_kernel_is_bit_identical(nat, case):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
+CONV64_CASES = [
+    # H, W, N, relu: layer1's map at batch 32 (12.5 tiles per persistent workgroup), partial tiles on both axes, one tile,
+    # fewer tiles than workgroups, a map smaller than a tile
+    (160, 160, 32, True), (72, 104, 3, True), (16, 16, 1, False), (40, 24, 7, True), (8, 8, 2, True), (50, 33, 5, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV64_CASES, ids=lambda c: "conv64_%dx%d_n%d_%d" % c)
+def test_persistent_64_channel_kernel_is_bit_identical(nat, case):
+    """csrc/conv64.hip (ConvTile kind 5; option "conv64"): conv2 + bn2 + relu of layer1's Bottlenecks (reference
+    pose_higher_hrnet.py:78-116: 3x3, 64 -> 64, stride 1) on persistent workgroups with double-buffered LDS-DMA halo tiles
+    and the weight fragments in registers.  Same k order and rounding points as the one-workgroup-per-tile kernel: the
+    same bits, whatever the number of tiles per workgroup, with partial tiles, with and without ReLU; and within the
+    fp16 steps of the PyTorch-CPU ops that test_conv_layer_vs_pytorch allows the other kernels"""
+    H, W, N, relu = case
+    g = torch.Generator().manual_seed(64 + H + W)
+    xh = torch.randn(N, H, W, 64, generator=g).half()
+    x = xh.to("cuda:0")
+    wt = ((torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / (64 * 9) ** 0.5).half().contiguous()
+    w = wt.numpy()
+    at = torch.rand(64, generator=g) * 0.4 + 0.8
+    bt = torch.randn(64, generator=g) * 0.1
+    a, b = at.numpy(), bt.numpy()
+    fp = ctypes.POINTER(ctypes.c_float)
+    L = nat.lib()
+    outs = []
+    try:
+        for on in (0, 1):
+            nat.check(L.rtpe_set_option(b"conv64", on))
+            y = torch.full((N, H, W, 64), float("nan"), dtype=torch.float16, device="cuda:0")
+            flags = (nat.F_RELU if relu else 0) | nat.F_ROUND_CONV
+            nat.check(L.rtpe_conv2d_nhwc(x.data_ptr(), N, H, W, 64, w.ctypes.data, a.ctypes.data_as(fp), b.ctypes.data_as(fp),
+                                         64, 3, 1, flags, None, y.data_ptr(), nat.stream_ptr(torch.device("cuda:0"))))
+            torch.cuda.synchronize()
+            outs.append(y.cpu())
+    finally:
+        nat.check(L.rtpe_set_option(b"conv64", 1))
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    if N * H * W <= 72 * 104 * 3:       # the reference's ops on the CPU (fp16 conv is slow there: the small cases)
+        yc = F.conv2d(xh.permute(0, 3, 1, 2), wt, None, 1, 1)
+        yb = (yc.float() * at.view(1, -1, 1, 1) + bt.view(1, -1, 1, 1)).half()
+        want = (F.relu(yb) if relu else yb).permute(0, 2, 3, 1).float().numpy()
+        got = outs[1].float().numpy()
+        scale = np.maximum(np.abs(want), np.abs(yb.permute(0, 2, 3, 1).float().numpy()))
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(scale, 0.25))) - 10)
+        err = np.abs(got - want) / ulp
+        assert err.max() <= 3.0 and (got == want).mean() > 0.99, (err.max(), (got == want).mean())
+
+
 @pytest.mark.parametrize("hw,n,f32in", [((64, 96), 2, True), ((160, 224), 3, True), ((32, 32), 1, False), ((96, 352), 2, True)])
 def test_stem_and_nchw_head_epilogues(nat, hw, n, f32in):
     """layer-level check of the two kernels that touch the NCHW boundary, through the ABI (rtpe_hrnet_create /
@@ -1795,7 +1845,7 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0",
-               RTPE_FUSED_STEM="0")
+               RTPE_FUSED_STEM="0", RTPE_CONV64="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
@@ -1844,7 +1894,7 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
-               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
