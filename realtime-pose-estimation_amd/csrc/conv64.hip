@@ -7,15 +7,18 @@
 //     halo tile of the NEXT tile (18 x 18 pixels x 160 bytes) by LDS-DMA into the other of two buffers, and the rows of
 //     the PREVIOUS tile out of a transpose buffer as 16-byte NHWC pieces (plain stores: write-through ones measured 12 %
 //     slower here) - while this tile is multiplied;
-//   * multiplier w owns cout tile w - its 18 weight fragments (the conv op's own packed plan: mt 4, one 64-channel chunk)
-//     stay in registers for the whole kernel - and the tile's 16 rows of 16 pixels in two halves: 8 B-operand reads (one
-//     k step ahead) and 8 MFMAs per k step, same k order as conv_mfma.hip (bit-identical, tests/test_gpu_parity.py).
+//   * multiplier w owns two cout tiles - their 36 weight fragments (the conv op's own packed plan: mt 4, one 64-channel
+//     chunk) stay in registers for the whole kernel - and 8 of the tile's 16 rows of 16 pixels in two passes of 4: 4
+//     B-operand reads (one k step ahead) and 8 MFMAs per k step, same k order as conv_mfma.hip (bit-identical,
+//     tests/test_gpu_parity.py).
 // LDS: 2 x 51,840 B of halo tiles + 36,864 B of transpose buffer = 137 KiB.
-// Measured at batch 32 (160 x 160 maps, tools/conv64_abl.sh): 81 us against 88-94 us on the one-workgroup-per-tile kernel
-// (HBM floor of the layer ~47 us); with parts switched off: no stores 62 us, no stores and no tile requests 60 us, nothing but
-// barriers and epilogue arithmetic 22 us - the k loops run at the LDS array's rate (every B fragment is read by the four
-// multipliers, one per cout tile: 1,152 KiB of operand reads per tile for 4,600 cycles of MFMAs), which two cout tiles per
-// wave would halve if their 144 weight registers fitted beside the accumulators.
+// Measured at batch 32 (160 x 160 maps, tools/conv64_abl.sh): 63 us against 88-94 us on the one-workgroup-per-tile kernel
+// (HBM floor of the layer ~47 us); with parts switched off: no stores 56 us, no stores and no tile requests 55 us, nothing but
+// barriers and epilogue arithmetic 22 us.  Steps on the way: all 8 waves multiplying AND moving data 116 us (a wave that
+// issues memory instructions issues no MFMAs meanwhile: requests 18 + stores 23 + k loops 50 us added up); 4 multipliers + 4
+// movers 98 us; the movers' eight LDS reads of a tile before their first store, plain stores 81 us; two cout tiles per
+// multiplier (half the B-operand reads) 82 us - no change: the k loops were not bound by the LDS array; the movers' stores
+// BEFORE their requests for the next tile (the stores gate barrier O, the requests have until the next T) 63 us.
 #include "rtpe_common.h"
 
 namespace rtpe {
@@ -131,10 +134,11 @@ __global__ void __launch_bounds__(kThreads) conv64_kernel(const ConvArgs a) {
     for (int t = t0; t < t_end; t += wg_per_xcd) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of tile t have landed (its older stores too)
       __syncthreads();                                    // T
-      if (t + wg_per_xcd < t_end && !(a.ablate & 4)) request_tile(t + wg_per_xcd, bufs + (cur ^ 1) * kBufBytes);
+      // the stores first: they gate O (the multipliers' epilogue); the requests for the next tile have until the next T
       if (prev >= 0 && !(a.ablate & 2)) store_rows(prev);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are in registers / on their way
       __syncthreads();                                    // O
+      if (t + wg_per_xcd < t_end && !(a.ablate & 4)) request_tile(t + wg_per_xcd, bufs + (cur ^ 1) * kBufBytes);
       prev = t;
       cur ^= 1;
     }
@@ -144,36 +148,43 @@ __global__ void __launch_bounds__(kThreads) conv64_kernel(const ConvArgs a) {
   }
 
   // ---------------------------------- multipliers: 4 waves ----------------------------------
-  // wave w owns cout tile w (its 18 weight fragments stay in registers) and all 16 rows of 16 pixels of the tile, in two
-  // halves of 8; the B operands of the next k step are requested before the MFMAs of the current one
+  // wave w owns TWO cout tiles (2 * (w & 1), + 1: their 36 weight fragments stay in registers) and 8 of the tile's 16 rows of
+  // 16 pixels (half w >> 1), in two passes of 4 rows: a B fragment feeds two MFMAs, so the LDS array serves half the
+  // operand reads of one cout tile per wave (which ran the k loops at the LDS array's rate: 57 us of an 81 us layer);
+  // the B operands of the next k step are requested before the MFMAs of the current one
   const int r = lane & 15, g = lane >> 4;
-  const int m = wv;
-  uint4 a_res[18];
-  {
-    const uint4* wfrag = reinterpret_cast<const uint4*>(a.w) + m * 64 + lane;
+  const int m0 = 2 * (wv & 1), hf = wv >> 1;
+  uint4 a_res[2][18];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) a_res[k] = wfrag[(size_t)k * 4 * 64];
+  for (int mm = 0; mm < 2; ++mm) {
+    const uint4* wfrag = reinterpret_cast<const uint4*>(a.w) + (m0 + mm) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a_res[mm][k] = wfrag[(size_t)k * 4 * 64];
   }
-  const float4v al = *reinterpret_cast<const float4v*>(a.alpha + m * 16 + g * 4);
-  const float4v be = *reinterpret_cast<const float4v*>(a.beta + m * 16 + g * 4);
-  const int bbase = r * kPS + g * 16;
+  float4v al[2], be[2];
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    al[mm] = *reinterpret_cast<const float4v*>(a.alpha + (m0 + mm) * 16 + g * 4);
+    be[mm] = *reinterpret_cast<const float4v*>(a.beta + (m0 + mm) * 16 + g * 4);
+  }
+  const int bbase = (hf * 8) * kRowB + r * kPS + g * 16;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int cur = 0;
   for (int t = t0; t < t_end; t += wg_per_xcd) {
     const char* tb = bufs + cur * kBufBytes + bbase;
     __syncthreads();                                      // T
-    float4v acc[2][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
+      float4v acc[2][4];                                  // [cout tile][row]
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) acc[h][nt] = float4v{0.f, 0.f, 0.f, 0.f};
-    if (!(a.ablate & 1)) {                                // (profiling ablations: RTPE_STREAM_ABL in diagnostic builds)
+      for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const char* th = tb + h * 8 * kRowB;
-        uint4 bf[2][8];
+        for (int nt = 0; nt < 4; ++nt) acc[mm][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+      if (!(a.ablate & 1)) {                              // (profiling ablations: RTPE_STREAM_ABL in diagnostic builds)
+        const char* th = tb + h * 4 * kRowB;
+        uint4 bf[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) bf[0][nt] = *reinterpret_cast<const uint4*>(th + nt * kRowB);
+        for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *reinterpret_cast<const uint4*>(th + nt * kRowB);
 #pragma unroll
         for (int kci = 0; kci < 18; ++kci) {
           const int cb = kci & 1, nb = cb ^ 1;
@@ -181,42 +192,48 @@ __global__ void __launch_bounds__(kThreads) conv64_kernel(const ConvArgs a) {
             const int tap = (kci + 1) >> 1, ty = tap / 3, tx = tap - ty * 3;
             const int ko = ty * kRowB + tx * kPS + ((kci + 1) & 1) * 64;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) bf[nb][nt] = *reinterpret_cast<const uint4*>(th + nt * kRowB + ko);
+            for (int nt = 0; nt < 4; ++nt) bf[nb][nt] = *reinterpret_cast<const uint4*>(th + nt * kRowB + ko);
           }
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt)
-            acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_res[kci]), __builtin_bit_cast(half8, bf[cb][nt]),
-                                                                acc[h][nt], 0, 0, 0);
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+              acc[mm][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_res[mm][kci]),
+                                                                   __builtin_bit_cast(half8, bf[cb][nt]), acc[mm][nt], 0, 0, 0);
           if (kci + 1 < 18) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int i = 0; i < 4; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
-    __syncthreads();                                      // O: the transpose buffer is free
-    // ---- BN (+ the conv output's own rounding) -> transpose buffer ----
+      // O sits behind the first pass: by then the movers have long read the previous tile's rows out of the transpose
+      // buffer, and the accumulators of a pass can leave right away (both passes' would not fit the registers)
+      if (h == 0) __syncthreads();                        // O: the transpose buffer is free
+      // ---- BN (+ the conv output's own rounding) -> transpose buffer ----
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        _Float16 o[4];
+        for (int mm = 0; mm < 2; ++mm) {
+          // (BatchNorm stays here: done by the movers on the row pieces they store - built and measured - it delays their
+          // stores, which gate O: 63 -> 71 us)
+          _Float16 o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float x = acc[h][nt][j];
-          if (a.round_conv) x = round16(x);
-          float tt = __builtin_fmaf(x, al[j], be[j]);
-          asm volatile("" : "+v"(tt));                   // (no fma + cast fusion: two roundings, conv_mfma.hip)
-          o[j] = (_Float16)tt;
+          for (int j = 0; j < 4; ++j) {
+            float x = acc[mm][nt][j];
+            if (a.round_conv) x = round16(x);
+            float tt = __builtin_fmaf(x, al[mm][j], be[mm][j]);
+            asm volatile("" : "+v"(tt));                   // (no fma + cast fusion: two roundings, conv_mfma.hip)
+            o[j] = (_Float16)tt;
+          }
+          unsigned long long raw;
+          __builtin_memcpy(&raw, o, 8);
+          *reinterpret_cast<unsigned long long*>(obuf + ((hf * 8 + h * 4 + nt) * 16 + r) * kObufRow + ((m0 + mm) * 16 + g * 4) * 2) = raw;
         }
-        unsigned long long raw;
-        __builtin_memcpy(&raw, o, 8);
-        *reinterpret_cast<unsigned long long*>(obuf + ((h * 8 + nt) * 16 + r) * kObufRow + (m * 16 + g * 4) * 2) = raw;
-      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     cur ^= 1;
   }
