@@ -772,15 +772,6 @@ static bool conv64_tile(const ConvPlan& p, int N, int H_pos, int W_pos, ConvTile
   return true;
 }
 
-static bool conv96_tile(const ConvPlan& p, int N, int H_pos, int W_pos, ConvTile* out) {
-  if (!conv96_supports(p) || get_option(kOptConv96) == 0) return false;
-  memset(out, 0, sizeof(*out));
-  out->kind = 6; out->nt = 1; out->waves = 8; out->th = 8; out->tw = 16;       // 8 x 16 = 16 x 1 x 8: the common check
-  out->grid = conv96_grid(N, H_pos, W_pos);
-  out->lds_bytes = conv96_lds();
-  return true;
-}
-
 ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool allow_direct, bool allow_conv64) {
   if (allow_direct) {
     ConvTile t;
@@ -789,7 +780,6 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool all
   if (allow_conv64) {
     ConvTile t;
     if (conv64_tile(p, N, H_pos, W_pos, &t)) return t;
-    if (get_option(kOptConv96) == 2 && conv96_tile(p, N, H_pos, W_pos, &t)) return t;   // (2: also for un-tuned launches)
   }
   if (get_option(kOptStreamPC) == 2 && conv_stream_pc_supports(p)) {
     ConvTile t = make_stream_pc_tile(p, N, H_pos, W_pos);
@@ -964,7 +954,6 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     ConvTile dt;
     if (direct_tile(p, &dt)) out->push_back(dt);                 // 1x1: no staged tile at all (conv_direct.hip)
     if (conv64_tile(p, N, H_pos, W_pos, &dt)) out->push_back(dt);   // 64 -> 64 3x3: persistent, pipelined (conv64.hip)
-    if (conv96_tile(p, N, H_pos, W_pos, &dt)) out->push_back(dt);   // 96 -> 96 3x3: all couts per workgroup (conv96.hip)
   }
 }
 
@@ -988,7 +977,6 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   if (t.kind == 3) return conv_stream_pc_launch(p, t, a, s);
   if (t.kind == 4) return conv_direct_launch(p, a, s);
   if (t.kind == 5) return conv64_launch(p, t, a, s);
-  if (t.kind == 6) return conv96_launch(p, t, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
                "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");
   const int mrun = t.mrun > 0 ? t.mrun : p.mt;

@@ -78,10 +78,10 @@ struct rtpe_hrnet {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "conv96"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_CONV96"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 1, 1, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -418,7 +418,7 @@ static std::vector<char> plane_tensors(const rtpe_hrnet* h, int N, int H, int W,
     const rtpe_tensor_desc& ti = h->tensors[d.in_t];
     const ConvTile t = (tuned && (*tuned)[i * 4].nt) ? (*tuned)[i * 4]
                                                       : conv_make_tile(o.plan[0], N, H >> ti.ds_log2, W >> ti.ds_log2);
-    if (t.kind != 2 && t.kind != 3 && t.kind != 6) {
+    if (t.kind != 2 && t.kind != 3) {
       plane[d.in_t] = plane[d.out_t] = 0;
       if (d.res_t >= 0) plane[d.res_t] = 0;
     }
@@ -733,9 +733,6 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         // the persistent 64 -> 64 kernel (conv64.hip) takes no residual and writes plain NHWC rows through one buffer window
         if (tile.kind == 5 && !(direct_ok && a.res == nullptr && !plane[d.in_t] && !plane[d.out_t]))
           tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos, true, /*allow_conv64=*/false);
-        // the all-couts 96 -> 96 kernel (conv96.hip) addresses its input through one buffer window and writes whole 96-channel rows
-        if (tile.kind == 6 && !(a.x_bytes < 0x80000000ull && a.y != nullptr && a.y_nchw == nullptr && a.o_mul == 1 && a.cout_store == 96))
-          tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos, true, /*allow_conv64=*/false);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
         if (merge) {
           // class k's weights and offsets go into the argument block of class 0; the launch follows the last class
@@ -965,7 +962,7 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   a.relu = (flags & RTPE_F_RELU) ? 1 : 0;
   a.round_conv = (flags & RTPE_F_ROUND_CONV) ? 1 : 0;
   const bool one_window = a.x_bytes < 0x80000000ull;
-  const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos, /*allow_direct=*/one_window, /*allow_conv64=*/one_window && (res == nullptr || cin != 64));
+  const ConvTile tile = conv_make_tile(p, N, a.H_pos, a.W_pos, /*allow_direct=*/one_window, /*allow_conv64=*/one_window && res == nullptr);
   // diagnostic builds, RTPE_PROBE_PLANE=1: time a streaming launch with plane-major views ([C/48][N][H][W][48], what the
   // engine gives the inner tensors of the C >= 96 block chains) over the same bytes - the values are then meaningless
   static const int probe_plane = RTPE_DIAG_ENV_INT("RTPE_PROBE_PLANE", 0);
@@ -1179,7 +1176,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     return RTPE_OK;
   }
   out8[0] = t.kind == 0 && t.mrun ? t.mrun : o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 5 ? -(500000 + t.grid) : t.kind == 6 ? -(400000 + t.grid) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 5 ? -(500000 + t.grid) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
                                                             : (int32_t)t.lds_bytes;   // pc: "/8" weight ring, "/9" resident weights
   return RTPE_OK;
 }

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kOptFusedStem = 7, kOptConv64 = 8, kOptConv96 = 9, kNumOptions = 10 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kOptFusedStem = 7, kOptConv64 = 8, kNumOptions = 9 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -186,7 +186,7 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   size_t lds_bytes;
   int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
                         // (conv_stream.hip), 3: streaming, producer / consumer wave groups (conv_stream_pc.hip), 4: direct 1x1
-                        // (conv_direct.hip), 5: 64 -> 64 3x3 on persistent workgroups (conv64.hip), 6: 96 -> 96 3x3, all couts per workgroup (conv96.hip)
+                        // (conv_direct.hip), 5: 64 -> 64 3x3 on persistent workgroups (conv64.hip)
   int grid;             // streaming: number of workgroups
   int buf_bytes;        // streaming: one LDS tile buffer
   int n_bufs;           // streaming: halo tile buffers
@@ -237,12 +237,6 @@ bool conv64_supports(const ConvPlan& p);
 size_t conv64_lds();
 int conv64_grid(int N, int H_pos, int W_pos);
 int conv64_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
-// 3x3 stride-1 96 -> 96 convs with all 96 output channels per workgroup: six multiplier waves keep the weight fragments
-// of one cout tile each in registers (conv96.hip, ConvTile::kind == 6: 8 x 16 tiles, 8 waves; NHWC or plane-major views)
-bool conv96_supports(const ConvPlan& p);
-size_t conv96_lds();
-int conv96_grid(int N, int H_pos, int W_pos);
-int conv96_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);

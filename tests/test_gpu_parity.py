@@ -202,47 +202,6 @@ def test_producer_consumer_streaming_kernel_is_bit_identical(nat, case):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
-CONV96_CASES = [
-    # H, W, N, residual + ReLU: the 96-channel branch's map at batch 32 (6.25 tiles per persistent workgroup), partial tiles
-    # on both axes, one tile, fewer tiles than workgroups, a map smaller than a tile
-    (80, 80, 32, True), (80, 80, 8, False), (37, 51, 3, True), (8, 16, 1, False), (40, 32, 5, True), (5, 7, 2, True),
-]
-
-
-@pytest.mark.parametrize("case", CONV96_CASES, ids=lambda c: "conv96_%dx%d_n%d_%d" % c)
-def test_all_couts_96_channel_kernel_is_bit_identical(nat, case):
-    """csrc/conv96.hip (ConvTile kind 6; option "conv96": 0 = never, 1 = one more launch shape for the autotuner, 2 = also
-    for un-tuned launches as here): the 3x3 convs of the 96-channel BasicBlocks (reference pose_higher_hrnet.py:46-75) with
-    all 96 output channels per workgroup - six multiplier waves hold the weight fragments of one cout tile each in
-    registers, two mover waves request halo tiles, load residual rows and store.  Same k order (chunk 0's k steps, then
-    chunk 1's) and rounding points as conv_stream_kernel: the same bits, whatever the number of tiles per workgroup, with
-    partial tiles, with and without residual / ReLU"""
-    H, W, N, use_res = case
-    g = torch.Generator().manual_seed(96 + H + W)
-    x = torch.randn(N, H, W, 96, generator=g).half().to("cuda:0")
-    w = ((torch.rand(96, 96, 3, 3, generator=g) * 2 - 1) / (96 * 9) ** 0.5).half().contiguous().numpy()
-    a = (torch.rand(96, generator=g) * 0.4 + 0.8).numpy()
-    b = (torch.randn(96, generator=g) * 0.1).numpy()
-    res = torch.randn(N, H, W, 96, generator=g).half().to("cuda:0") if use_res else None
-    fp = ctypes.POINTER(ctypes.c_float)
-    L = nat.lib()
-    outs = []
-    try:
-        for on in (0, 2):
-            nat.check(L.rtpe_set_option(b"conv96", on))
-            y = torch.full((N, H, W, 96), float("nan"), dtype=torch.float16, device="cuda:0")
-            flags = (nat.F_RELU if use_res else 0) | nat.F_ROUND_CONV
-            nat.check(L.rtpe_conv2d_nhwc(x.data_ptr(), N, H, W, 96, w.ctypes.data, a.ctypes.data_as(fp), b.ctypes.data_as(fp),
-                                         96, 3, 1, flags, res.data_ptr() if use_res else None, y.data_ptr(),
-                                         nat.stream_ptr(torch.device("cuda:0"))))
-            torch.cuda.synchronize()
-            outs.append(y.cpu())
-    finally:
-        nat.check(L.rtpe_set_option(b"conv96", 1))
-    assert not torch.isnan(outs[1].float()).any()
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
-
-
 CONV64_CASES = [
     # H, W, N, relu: layer1's map at batch 32 (12.5 tiles per persistent workgroup), partial tiles on both axes, one tile,
     # fewer tiles than workgroups, a map smaller than a tile
@@ -1886,7 +1845,7 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0",
-               RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_CONV96="0")
+               RTPE_FUSED_STEM="0", RTPE_CONV64="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
@@ -1935,7 +1894,7 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
-               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_CONV96="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
