@@ -424,6 +424,41 @@ def test_stream_kernel_register_window_is_not_allocated(built, tmp_path):
     assert n_window > 0
 
 
+def _device_code(built, tmp_path, name):
+    """disassembly of the gfx950 code object inside build/<name>.o (a copy: the test must not touch build products)"""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    obj = shutil.copy(os.path.join(os.path.dirname(built.LIB_PATH), "build", name + ".o"), str(tmp_path / (name + ".o")))
+    fat, co = str(tmp_path / (name + ".fatbin")), str(tmp_path / (name + ".co"))
+    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, str(tmp_path / (name + ".2.o"))], check=True)
+    subprocess.run([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--input=" + fat, "--output=" + co], check=True)
+    return subprocess.run([llvm + "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+
+
+def test_rounding_points_survive_the_compiler(built, tmp_path):
+    """the half wrapper rounds a conv output and a BatchNorm output separately (two fp16 tensors in the reference).  The
+    compiler fuses an fp32 fma whose result is cast to fp16 into v_fma_mixlo_f16 / v_fma_mixhi_f16, which rounds the exact
+    a * b + c ONCE (one output in ~40,000 then differs by an fp16 step); every epilogue keeps the fma's result opaque to
+    prevent that.  No conv kernel of the build may contain the fused form.  And the kernels of round 4 keep their design
+    points: the fused stem runs conv1's fp32 chain on the matrix pipe (v_mfma_f32_16x16x4_f32), neither it nor the
+    64-channel kernel spills registers to scratch memory"""
+    import re
+    for name in ("conv_mfma.hip", "conv_stream.hip", "conv_stream_pc.hip", "conv_block.hip", "conv_direct.hip", "conv_pair.hip",
+                 "stem_fused.hip", "conv64.hip"):
+        dis = _device_code(built, tmp_path, name)
+        fused = re.findall(r"v_fma_mix(?:lo|hi)_f16", dis)
+        assert not fused, "%s: %d fused fma + fp16 conversions" % (name, len(fused))
+        if name in ("stem_fused.hip", "conv64.hip"):
+            assert "scratch_" not in dis, name + ": registers spilled to scratch memory"
+    dis = _device_code(built, tmp_path, "stem_fused.hip")
+    assert dis.count("v_mfma_f32_16x16x4_f32") >= 4 * 7 and dis.count("v_mfma_f32_16x16x32_f16") >= 72
+    dis = _device_code(built, tmp_path, "elementwise.hip")
+    body = dis[dis.index("stem_kernelIDF16_"):] if "stem_kernelIDF16_" in dis else dis
+    assert not re.findall(r"v_fma_mix(?:lo|hi)_f16", body.split("s_endpgm")[0]), "stem_kernel<half>: fused fma + conversion"
+
+
 def test_compiled_engines_follow_the_weights(built, w48_shapes):
     """the executor holds a snapshot of the weights: in-place updates (load_state_dict on a sub-module,
     optimizer-style copy_, init_weights) must be noticed, a .to() that changes nothing must keep the engines, and a
