@@ -3,6 +3,7 @@
 at 640x640 on N MI355X (one process per GPU, RCCL).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N ranks as a child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -46,6 +47,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op table to this file")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL on a GPU, gloo without)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="no GPU work: the control path of the benchmark only (rank start-up, process group, weight "
+                         "broadcast, shards, record gather with faked decode results, barrier + max-over-ranks timing); "
+                         "for CPU tests of the launcher, with --backend gloo.  The line says so and carries no rate")
     ap.add_argument("--list", default="", help="configs[3]: a file of image names (one per line, e.g. tests/golden/"
                                                "coco_minival2017_100.txt); a step = one pass over the whole list, "
                                                "sharded contiguously over the ranks, uneven shards, short last batches, "
@@ -293,14 +298,92 @@ def run_other_config(args, dev):
         "roofline": roof, "cpu_baseline": None}))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves, as a
+    CHILD process (never exec: a process that has touched the GPU must not be replaced, and this one has not touched
+    it yet), with the same arguments; rank 0's JSON line passes through on the inherited stdout, the child's return
+    code is ours.  One rank per GPU over RCCL, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                 # what torchrun would set itself (and warn about)
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_rehearsal(args, rank, world):
+    """--rehearsal: everything of a multi-rank benchmark run except the GPU work, on the host: process group (gloo),
+    weight broadcast as packed buffers, contiguous shards, fixed-size records of faked decode results all-gathered
+    per step, barrier-bracketed timing with the max over ranks.  The collective code is rtpe.engine's, the one that
+    runs on RCCL; nothing here touches a device."""
+    import torch.distributed as dist
+    from rtpe import engine
+    sd = {"w": torch.arange(12.).reshape(3, 4), "h": torch.ones(5).half(), "n": torch.tensor(7)} if rank == 0 else \
+        {"w": torch.zeros(3, 4), "h": torch.zeros(5).half(), "n": torch.tensor(0)}
+    sd = engine.broadcast_state_dict(sd, 0, "cpu")
+    assert sd["w"][2, 3] == 11. and int(sd["n"]) == 7, "weight broadcast"
+    B = args.batch
+    ids = [rank * B + i for i in range(B)]
+    fake = [(np.full((1 + i % 3, 17, 4), float(i), np.float32), [float(i % 7)] * (1 + i % 3)) for i in ids]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    n_rec = 0
+    for _ in range(args.warmup):
+        engine.all_gather_records(engine.pack_records(ids, fake, "cpu"), equal_counts=True) if world > 1 else None
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = engine.pack_records(ids, fake, "cpu")
+        allrec = engine.all_gather_records(rec, equal_counts=True) if world > 1 else rec
+        n_rec = allrec.shape[0]
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    got = sorted(engine.unpack_records(allrec))
+    assert got == list(range(world * B)), "gathered records of %d images, expected %d" % (len(got), world * B)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec at 640x640 (HRNet-w48 fwd+decode)", "value": None, "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax.item()) / max(1, args.steps) * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (rehearsal)", "data": "synthetic",
+            "rehearsal": True,
+            "config": {"workload": "REHEARSAL of the control path only: %d rank(s), %s backend, weight broadcast, %d faked "
+                                   "records per rank and step all-gathered, no GPU work - not a measurement" % (
+                                       world, args.backend or "gloo", B),
+                       "records_gathered": int(n_rec)},
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing has touched the GPU yet (importing torch does not): the ranks are a child of this process
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     import torch.distributed as dist
+    if args.rehearsal:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend or "gloo", rank=rank, world_size=world)
+        return run_rehearsal(args, rank, world)
     from rtpe import _native as nat
     # RTPE_BENCH_SHARE_GPU=1: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
     # devices; use --backend gloo, RCCL refuses two ranks on one device).  Not a scaling measurement.
@@ -520,16 +603,31 @@ def main():
         kinds = sorted({"conv_stream_pc_kernel<%d>" % t[1] if t[7] <= -800000 else "conv_stream_kernel<3,%d,%d>" % (t[1], t[2]) if t[7] <= -100000
                         else "conv_mfma_kernel" for t in tiles})
         cnt = {}
+        tr_sum = tr_n = 0.0
         for kn in kinds:
             ent = pj.get("kernels", {}).get(kn.replace(" ", "")) or pj.get("kernels", {}).get(kn.replace(",", ", "))
             if ent and same_sources:
                 cls = next(iter(ent.get("classes", {}).values()), ent)
-                cnt[kn] = {k: cls[k] for k in ("mfma_util", "wait_any_frac", "lds_bank_conflict_frac", "us_under_profiler") if k in cls}
-        td = {"kernel": " + ".join(kinds) + ": 3x3 s1 convs with C in {96, 192, 384}, %d launches/forward" % len(td_idx),
+                cnt[kn] = {k: cls[k] for k in ("mfma_util", "wait_any_frac", "lds_bank_conflict_frac", "us_under_profiler",
+                                               "hbm_bytes_per_launch") if k in cls}
+                if "hbm_bytes_per_launch" in cls:
+                    n_l = float(cls.get("launches_per_pass", 1))
+                    tr_sum += float(cls["hbm_bytes_per_launch"]) * n_l
+                    tr_n += n_l
+        td_launch_s = td_ms * 1e-3 / len(td_idx)
+        td = {"kernel": " + ".join(kinds) + ": 3x3 s1 convs with C in {96, 192, 384}, %d launches/forward "
+                        "(the TIME-dominant family of the forward)" % len(td_idx),
               "bound": "mfma", "achieved": round(td_flops / (td_ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
-              "frac": round(td_flops / (td_ms * 1e-3) / 1e12 / MFMA_PEAK_TFS, 4), "ms_per_forward": round(td_ms, 3),
-              "share_of_forward": round(td_ms / fwd_ms_events, 3), "counters": cnt or None,
-              "traffic_measured_in_this_run": False}
+              "frac": round(td_flops / (td_ms * 1e-3) / 1e12 / MFMA_PEAK_TFS, 4),
+              "achieved_basis": "algorithmic FLOPs of a launch (2 * 9 * Cin * Cout * pixels, 33.97 GFLOP for every class at batch "
+                                "32) / mean HIP-event duration of a launch over the recorded steps",
+              # HBM bytes per launch by the counters (mean over the family's launches of the PMC passes of this command,
+              # committed under profiles/; attached only when made from the same kernel sources)
+              "traffic": round(tr_sum / tr_n, 1) if tr_n else None,
+              "traffic_source": os.path.relpath(args.pmc_json, ROOT) if tr_n else None, "traffic_measured_in_this_run": False,
+              "launch_us": round(td_launch_s * 1e6, 2), "flops_per_launch": td_flops / len(td_idx),
+              "ms_per_forward": round(td_ms, 3),
+              "share_of_forward": round(td_ms / fwd_ms_events, 3), "counters": cnt or None}
     if args.dump_ops:
         with open(args.dump_ops, "w") as f:
             f.write("# per-op-class HIP-event times, batch %d, %dx%d, avg over %d steps\n" % (B, S, S, args.steps))
@@ -559,7 +657,10 @@ def main():
                                "decode of batch k-1 beside forward k; the %d recorded steps run alone" % (
                                    os.environ.get("RTPE_FORWARDS_IN_FLIGHT", "2"), n_slots),
                    "forward_only_images_per_sec_per_gpu": round(B / fwd_s, 1)},
-        "roofline": roofline, "roofline_time_dominant": td, "cpu_baseline": cpu,
+        # roofline = the time-dominant kernel family (MFMA-bound 3x3 convs with C >= 96); roofline_secondary = the fused
+        # C = 48 BasicBlock (HBM-bound by SURVEY 8d's layer-fused bytes), the second-largest share of the forward
+        "roofline": td if td is not None else roofline, "roofline_secondary": roofline if td is not None else None,
+        "build_mode": entry.BUILD_INFO.get("mode"), "cpu_baseline": cpu,
     }
     print(json.dumps(out))
     if world > 1:
@@ -568,4 +669,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -65,7 +65,10 @@ extern "C" {
 #define RTPE_DTYPE_F32 2
 
 const char* rtpe_last_error_string(void);
-/* ABI revision: 3 = tuned-shape records have 11 integers (RTPE_TUNED_INTS);
+/* ABI revision: 4 = option "stream_pc" and ConvTile kind 3 are gone (a tuned-shape
+ * file that names kind 3 is refused by rtpe_hrnet_import_tuned); the Python binding
+ * refuses a library of another revision (RTPE_LIBRARY);
+ * 3 = tuned-shape records have 11 integers (RTPE_TUNED_INTS);
  * 2 = rtpe_op_desc carries lane / region (sizeof 112 -> 120),
  * rtpe_hrnet_forward_flags exists.  A caller built against revision 1 must
  * not pass its descriptors to this library: check before rtpe_hrnet_create. */
@@ -253,12 +256,7 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * variants for A/B measurements in one process).  "block_pc" = 0: the fused BasicBlock never runs on the
  * producer / consumer kernel (default 1: wherever H % 8 == 0 and W % 16 == 0; env RTPE_BLOCK_PC).  "block_ring" = 1:
  * the fused BasicBlock kernel streams its weights through a 3-slot LDS ring instead of keeping them resident
- * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc").  "stream_pc" (env RTPE_STREAM_PC): the
- * producer / consumer streaming conv kernel for the 3x3 stride-1 convs with 48-channel chunks (csrc/conv_stream_pc.hip: two
- * wave groups alternate over the units, one multiplies while the other finishes the previous unit) is 0 = never used
- * (default: measured equal to or slower than the first streaming kernel on every layer class, DESIGN.md section 4 "Round 4"),
- * 1 = one more family of launch shapes for the autotuner,
- * 2 = the only streaming kernel (also for un-tuned launches: the layer-level tests run it this way).  "direct_1x1" (env
+ * (default 0; env RTPE_BLOCK_RING; takes precedence over "block_pc").  "direct_1x1" (env
  * RTPE_DIRECT_1X1): the 1x1 conv kernel without a staged input tile (csrc/conv_direct.hip) is 0 = never used, 1 = one more launch
  * shape for the autotuner and the default of un-tuned launches (default), 2 = as 1 (reserved).  "lanes" (env RTPE_LANES): the
  * independent branches of a parallel region run 0 = one after another on the caller's stream, 1 = concurrently on internal

@@ -241,8 +241,10 @@ __global__ void __launch_bounds__(kThreads) conv64_kernel(const ConvArgs a) {
 }
 
 bool conv64_supports(const ConvPlan& p) {
+  // a real 64 -> 64 layer only: cin 49..63 / cout 49..63 give the same padded plan (cc 64, one chunk, cout_pad 64) but
+  // rows that this kernel's fixed 128-byte pixel pieces do not describe - they stay on the one-workgroup-per-tile kernel
   return p.esize == 2 && p.dil == 1 && p.tapw == 3 && p.in_mul == 1 && p.mt == 4 && p.cc == 64 && p.n_cchunks == 1 && p.kc == 18 &&
-         p.n_cb == 1 && p.cout_pad == 64;
+         p.n_cb == 1 && p.cout_pad == 64 && p.cin == 64 && p.cout == 64;
 }
 
 size_t conv64_lds() { return kLds; }

@@ -504,6 +504,8 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
   const bool dc = g.deconv_class >= 0;
   p.tapw = dc ? 2 : g.ksize;
   p.in_mul = dc ? 1 : g.stride;
+  p.cin = g.cin;
+  p.cout = g.cout;
   if (dc) {
     p.lo_y = (g.deconv_class >> 1) == 0 ? -1 : 0;
     p.lo_x = (g.deconv_class & 1) == 0 ? -1 : 0;
@@ -681,32 +683,6 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   return true;
 }
 
-// producer / consumer streaming kernel (conv_stream_pc.hip, kind 3): the launch shapes of the streaming kernel with 4
-// pixel-tile waves (x 2 groups), two halo buffers and NO output slab: a buffer holds the halo tile only
-static bool stream_pc_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, int W_pos, bool want_resident, ConvTile* out) {
-  if (!conv_stream_pc_supports(p) || c.waves != 4 || (c.nt != 4 && c.nt != 5)) return false;
-  const int hh = c.th + 2, hw = c.tw + 2;
-  if (hw * 6 > 256 || c.th > 255 || c.tw > 255) return false;
-  size_t buf = (size_t)hh * conv_row_pitch(p, c.tw, 2);
-  buf = (buf + 255) / 256 * 256;
-  const bool resident = want_resident && p.n_cchunks <= 2 && conv_stream_pc_lds(p, (int)buf, 2 * p.n_cchunks) <= 160 * 1024;
-  if (want_resident != resident) return false;
-  const int nw = resident ? 2 * p.n_cchunks : 3;
-  if (conv_stream_pc_lds(p, (int)buf, nw) > 160 * 1024) return false;
-  const long tiles = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N;
-  const long units = tiles * p.n_cb;
-  long G = 32;                                            // one workgroup per CU
-  const long need = (units + 7) / 8;
-  if (G > need) G = need;
-  G = (G + p.n_cb - 1) / p.n_cb * p.n_cb;
-  memset(out, 0, sizeof(*out));
-  out->nt = c.nt; out->waves = 4; out->th = c.th; out->tw = c.tw;
-  out->kind = 3; out->grid = (int)(8 * G); out->buf_bytes = (int)buf; out->n_bufs = 2;
-  out->n_wslots = nw;
-  out->lds_bytes = conv_stream_pc_lds(p, (int)buf, nw);
-  return true;
-}
-
 static ConvTile make_stream_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
   static const int force_nt = RTPE_DIAG_ENV_INT("RTPE_CONV_NT", 0);
   static const int force_waves = RTPE_DIAG_ENV_INT("RTPE_CONV_WAVES", 0);
@@ -729,27 +705,6 @@ static ConvTile make_stream_tile(const ConvPlan& p, int N, int H_pos, int W_pos)
     const double score = waste * imbalance * (1.0 + 0.15 * (halo - 1.0)) * (t.n_bufs == 3 ? 1.0 : 1.05) *
                          (c.waves == 5 ? 1.3 : 1.0) * (t.n_wslots == 3 ? 1.0 : 0.8);
     if (score < best_score) { best_score = score; best = t; }
-  }
-  return best;
-}
-
-static ConvTile make_stream_pc_tile(const ConvPlan& p, int N, int H_pos, int W_pos) {
-  double best_score = 1e30;
-  ConvTile best;
-  memset(&best, 0, sizeof(best));
-  for (const TileCand& c : kCands) {
-    for (int res = 1; res >= 0; --res) {
-      ConvTile t;
-      if (!stream_pc_tile(p, c, N, H_pos, W_pos, res != 0, &t)) continue;
-      const double waste = (double)((H_pos + c.th - 1) / c.th * c.th) * ((W_pos + c.tw - 1) / c.tw * c.tw) /
-                           ((double)H_pos * W_pos);
-      const long units = (long)((H_pos + c.th - 1) / c.th) * ((W_pos + c.tw - 1) / c.tw) * N * p.n_cb;
-      const double rounds = (double)units / t.grid;
-      const double imbalance = rounds >= 1.0 ? (double)((long)(rounds + 0.999)) / rounds : 1.0;
-      const double halo = (double)(c.th + 2) * (c.tw + 2) / ((double)c.th * c.tw);
-      const double score = waste * imbalance * (1.0 + 0.15 * (halo - 1.0)) * (res ? 0.8 : 1.0);
-      if (score < best_score) { best_score = score; best = t; }
-    }
   }
   return best;
 }
@@ -780,10 +735,6 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool all
   if (allow_conv64) {
     ConvTile t;
     if (conv64_tile(p, N, H_pos, W_pos, &t)) return t;
-  }
-  if (get_option(kOptStreamPC) == 2 && conv_stream_pc_supports(p)) {
-    ConvTile t = make_stream_pc_tile(p, N, H_pos, W_pos);
-    if (t.nt) return t;
   }
   static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
   if ((stream & 1) && conv_stream_supports(p)) {
@@ -866,10 +817,6 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->buf_bytes = t.buf_bytes;
   a->n_bufs = t.n_bufs;
   a->n_wslots = t.n_wslots;
-  if (t.kind == 3) {
-    static const int pcf = RTPE_DIAG_ENV_INT("RTPE_PC_FLAGS", 0);     // diagnostic builds: 2 / 4 (rtpe_common.h)
-    a->pc_flags = pcf;
-  }
   static const int abl = RTPE_DIAG_ENV_INT("RTPE_STREAM_ABL", 0);
   a->ablate = abl;
   // ablations for profiling only (-DRTPE_DIAG builds): RTPE_CONV_SKIPK=1 runs the data movement without the k-loops
@@ -936,18 +883,13 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
         if (t.lds_bytes <= 160 * 1024) out->push_back(t);
       }
     static const int stream = getenv("RTPE_CONV_STREAM") ? atoi(getenv("RTPE_CONV_STREAM")) : 1;
-    if ((stream & 1) && get_option(kOptStreamPC) != 2) {
+    if (stream & 1) {
       ConvTile st;
       if (stream_tile(p, c, N, H_pos, W_pos, &st)) out->push_back(st);   // streaming, LDS-DMA operands
       // two-chunk layers: resident weights leave room for 2 halo buffers, the weight ring for 3
       if (p.n_cchunks == 2 && st.nt && st.n_wslots != 3 && stream_tile(p, c, N, H_pos, W_pos, &st, false) &&
           st.n_bufs == 3)
         out->push_back(st);
-    }
-    if ((stream & 1) && get_option(kOptStreamPC) != 0) {           // producer / consumer wave groups (conv_stream_pc.hip)
-      ConvTile st;
-      for (int res = 1; res >= 0; --res)
-        if (stream_pc_tile(p, c, N, H_pos, W_pos, res != 0, &st)) out->push_back(st);
     }
   }
   {
@@ -974,7 +916,6 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   RTPE_REQUIRE(a.res == nullptr || (a.res_ld % eps == 0 && ((uintptr_t)a.res & 15) == 0), "conv: residual view alignment");
   RTPE_REQUIRE(((uintptr_t)a.x & 15) == 0, "conv: input view must be 16-byte aligned");
   if (t.kind == 2) return conv_stream_launch(p, t, a, s);
-  if (t.kind == 3) return conv_stream_pc_launch(p, t, a, s);
   if (t.kind == 4) return conv_direct_launch(p, a, s);
   if (t.kind == 5) return conv64_launch(p, t, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,

@@ -1,4 +1,4 @@
-// Device-side helpers shared by the streaming conv kernels (conv_stream.hip, conv_stream_pc.hip).
+// Device-side helpers of the streaming conv kernel (conv_stream.hip) and the kernels built on its structure.
 #pragma once
 #include <type_traits>
 

@@ -78,10 +78,10 @@ struct rtpe_hrnet {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "stream_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_STREAM_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 0, 1, 1, 1, 1, 1, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -115,7 +115,7 @@ extern "C" int rtpe_get_option(const char* name, int32_t* value) {
 }
 
 extern "C" const char* rtpe_last_error_string(void) { return g_err.c_str(); }
-extern "C" int rtpe_version(void) { return 3; }   // 3: 11 integers per tuned record; 2: rtpe_op_desc has lane / region, rtpe_hrnet_forward_flags
+extern "C" int rtpe_version(void) { return 4; }   // 4: no "stream_pc" / kind 3; 3: 11 integers per tuned record; 2: rtpe_op_desc has lane / region, rtpe_hrnet_forward_flags
 extern "C" int rtpe_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -418,7 +418,7 @@ static std::vector<char> plane_tensors(const rtpe_hrnet* h, int N, int H, int W,
     const rtpe_tensor_desc& ti = h->tensors[d.in_t];
     const ConvTile t = (tuned && (*tuned)[i * 4].nt) ? (*tuned)[i * 4]
                                                       : conv_make_tile(o.plan[0], N, H >> ti.ds_log2, W >> ti.ds_log2);
-    if (t.kind != 2 && t.kind != 3) {
+    if (t.kind != 2) {
       plane[d.in_t] = plane[d.out_t] = 0;
       if (d.res_t >= 0) plane[d.res_t] = 0;
     }
@@ -551,6 +551,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
   ConvArgs pair_args;
   memset(&pair_args, 0, sizeof(pair_args));
   bool pair_pending = false;                              // the head of a 1x1 pair waits for its tail's launch
+  bool stem_pending = false;                              // the fused stem kernel ran at the stem op: the next op (conv2) is done
   int cur_region = 0;
   bool lane_used[4] = {false, false, false, false};
   auto join_lanes = [&]() -> hipError_t {
@@ -582,7 +583,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       if (cur_region > 0) {
         if (d.lane > 0) { s = h->lane_stream[d.lane]; lane_used[d.lane] = true; }
         for (int j : h->wait_ops[i]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
-        if (o.fuse == 1 && i + 1 < h->ops.size())        // the block's second conv is launched with this one
+        if ((o.fuse == 1 || o.stem2 == 1) && i + 1 < h->ops.size())   // the block's second conv (the stem's conv2) is launched with this one
           for (int j : h->wait_ops[i + 1]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
       }
     }
@@ -605,8 +606,9 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       a.relu = (d2.flags & RTPE_F_RELU) ? 1 : 0;
       a.round_conv = (d2.flags & RTPE_F_ROUND_CONV) ? 1 : 0;
       RTPE_HP_LAUNCH(rc = stem_fused_launch(a, s));
-    } else if (d.kind == RTPE_OP_CONV && o.stem2 == 2 && stem_fused_on) {
-      // done by the launch at the stem op
+      stem_pending = true;      // latched here: the option is process-wide and may change between this op and the next
+    } else if (d.kind == RTPE_OP_CONV && o.stem2 == 2 && stem_pending) {
+      stem_pending = false;     // done by the launch at the stem op
     } else if (d.kind == RTPE_OP_STEM && !(d.flags & RTPE_F_F32) && get_option(kOptFusedStem) == 2 && stem_fused_supports(H, W)) {
       // option "fused_stem" = 2: the stem op alone on the fused kernel's conv1 code (the chain on the matrix pipe),
       // output to memory - the bit-identity test of that chain against the VALU kernel
@@ -731,7 +733,8 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         const bool direct_ok = a.x_bytes < 0x80000000ull && a.y != nullptr && a.y_nchw == nullptr && a.o_mul == 1;
         if (tile.kind == 4 && !direct_ok) tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos, /*allow_direct=*/false);
         // the persistent 64 -> 64 kernel (conv64.hip) takes no residual and writes plain NHWC rows through one buffer window
-        if (tile.kind == 5 && !(direct_ok && a.res == nullptr && !plane[d.in_t] && !plane[d.out_t]))
+        // (also when a tuned or imported shape says kind 5 but option "conv64" has been switched off since)
+        if (tile.kind == 5 && !(direct_ok && a.res == nullptr && !plane[d.in_t] && !plane[d.out_t] && get_option(kOptConv64) != 0))
           tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos, true, /*allow_conv64=*/false);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
         if (merge) {
@@ -966,7 +969,7 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   // diagnostic builds, RTPE_PROBE_PLANE=1: time a streaming launch with plane-major views ([C/48][N][H][W][48], what the
   // engine gives the inner tensors of the C >= 96 block chains) over the same bytes - the values are then meaningless
   static const int probe_plane = RTPE_DIAG_ENV_INT("RTPE_PROBE_PLANE", 0);
-  if (probe_plane && (tile.kind == 2 || tile.kind == 3) && cin % 48 == 0 && cout % 48 == 0 && stride == 1) {
+  if (probe_plane && tile.kind == 2 && cin % 48 == 0 && cout % 48 == 0 && stride == 1) {
     a.in_ld = 48; a.in_cs = (long long)N * H * W * 48;
     a.out_ld = 48; a.out_cs = (long long)N * H * W * 48;
     if (res != nullptr) { a.res_ld = 48; a.res_cs = (long long)N * H * W * 48; }
@@ -992,14 +995,6 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
             tile.th, tile.tw, tile.nt, tile.waves, tile.n_bufs, tile.n_wslots, tile.grid, hd[15] / nw, units / nw, hd[0] / hd[5], hd[1] / hd[5],
             hd[2] / hd[5], hd[3] / hd[5], hd[12] / units, hd[13] / units, hd[4] / units, hd[14] / units, hd[10] / units, hd[6] / hd[11],
             hd[7] / hd[11], hd[8] / hd[11], hd[9] / hd[11]);
-  }
-  else if (tile.kind == 3 && hd[5]) {
-    // conv_stream_pc.hip: slots 0-3 / 5 = multiplying group per stage, 6-9 / 11 = finishing group per stage
-    const unsigned long long nw = (unsigned long long)tile.grid * 8, ks = hd[5], es = hd[11] ? hd[11] : 1;
-    fprintf(stderr, "stream pc conv %dx%d nt%d grid %d wslots %d flags %d | per wave: total %llu cycles (prologue %llu, last epilogue %llu) | multiplying group per stage: waitM %llu half0 %llu "
-            "waitH %llu half1 %llu | finishing group per stage: waitM %llu requests %llu epilogue %llu (H, requests, final wait) %llu\n",
-            tile.th, tile.tw, tile.nt, tile.grid, tile.n_wslots, a.pc_flags, hd[15] / nw, hd[12] / nw, hd[13] / nw, hd[0] / ks, hd[1] / ks, hd[2] / ks, hd[3] / ks,
-            hd[6] / es, hd[7] / es, hd[8] / es, hd[9] / es);
   }
   else if (hd[5])
     fprintf(stderr, "conv stamps (kind %d): n %llu | per wave(-unit) cycles: setup %llu stage/wait1 %llu kloop %llu epilogue %llu total/wait2 %llu\n",
@@ -1176,8 +1171,8 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     return RTPE_OK;
   }
   out8[0] = t.kind == 0 && t.mrun ? t.mrun : o.plan[0].mt; out8[1] = t.nt; out8[2] = t.waves; out8[3] = t.th; out8[4] = t.tw;
-  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 5 ? -(500000 + t.grid) : t.kind == 3 ? -(t.grid + 100000 * (t.n_wslots == 3 ? 8 : 9))
-                                                            : (int32_t)t.lds_bytes;   // pc: "/8" weight ring, "/9" resident weights
+  out8[5] = o.plan[0].cc; out8[6] = o.plan[0].n_cb; out8[7] = t.kind == 2 ? -(t.grid + 100000 * t.n_bufs) : t.kind == 4 ? -(700000 + t.grid) : t.kind == 5 ? -(500000 + t.grid)
+                                                            : (int32_t)t.lds_bytes;
   return RTPE_OK;
 }
 
@@ -1257,6 +1252,12 @@ static int autotune_impl(rtpe_hrnet* h, const void* x, int32_t x_dtype, const vo
     Class& c = kv.second;
     if (c.t.empty()) continue;
     size_t bi = 0;
+    double t_max = 0.0;
+    for (size_t j = 0; j < c.t.size(); ++j) t_max = c.t[j] > t_max ? c.t[j] : t_max;
+    // a class whose ops never ran on their own in these forwards (the second conv of a fused BasicBlock, the stem's conv2
+    // inside the fused stem kernel: their time is the head's, theirs reads 0) has nothing to choose from: it stays
+    // untuned, and whoever switches the fusion off gets the default launch shape instead of "the first candidate"
+    if (t_max <= 0.0) continue;
     for (size_t j = 1; j < c.t.size(); ++j) if (c.t[j] < c.t[bi]) bi = j;
     for (size_t i : c.ops)
       for (size_t k = 0; k < c.cands.size(); ++k) best[i * 4 + k] = c.cands[k][bi];

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptStreamPC = 2, kOptDirect1x1 = 3, kOptLanes = 4, kOptTileDma = 5, kOptPair1x1 = 6, kOptFusedStem = 7, kOptConv64 = 8, kNumOptions = 9 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -165,8 +165,6 @@ struct ConvArgs {
   int n_even;
   int m_split;           // one-workgroup-per-tile kernel: workgroups that share one packed cout block (ConvTile::mrun cout
                          // tiles each); 0 / 1 = one workgroup computes the whole block
-  int pc_flags;          // streaming pc kernel, diagnostic switches: 2 = the tile of the next stage is requested in two halves
-                         // around the mid-stage barrier (weight ring only), 4 = plain instead of write-through row stores
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
   unsigned long long* dbg;  // diagnostic builds only (-DRTPE_CONV_STAMPS): per-segment cycle sums
 };
@@ -177,6 +175,7 @@ struct ConvPlan {       // weight-layout half of the plan (fixed at create time)
   int tapw, in_mul, lo_y, lo_x;
   int esize, dil;       // bytes per element (2 fp16 / 4 fp32), dilation
   int cout_pad, n_cb;   // cout rounded up to 16*mt; number of cout blocks
+  int cin, cout;        // the layer's logical channel counts (kernels for ONE layer shape test these, not the padded ones)
   size_t packed_bytes;  // bytes of packed weights (all cout blocks)
 };
 
@@ -185,7 +184,7 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int th, tw;
   size_t lds_bytes;
   int kind;             // 0: one workgroup per tile (conv_mfma.hip), 2: streaming, weights and halos by LDS-DMA
-                        // (conv_stream.hip), 3: streaming, producer / consumer wave groups (conv_stream_pc.hip), 4: direct 1x1
+                        // (conv_stream.hip), 4: direct 1x1
                         // (conv_direct.hip), 5: 64 -> 64 3x3 on persistent workgroups (conv64.hip)
   int grid;             // streaming: number of workgroups
   int buf_bytes;        // streaming: one LDS tile buffer
@@ -220,11 +219,6 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
 bool conv_stream_supports(const ConvPlan& p);
 size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslots);
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
-// producer / consumer streaming kernel (conv_stream_pc.hip, ConvTile::kind == 3): eight waves in two groups that alternate
-// over the units - one multiplies while the other finishes the previous unit and requests operands; two halo buffers
-bool conv_stream_pc_supports(const ConvPlan& p);
-size_t conv_stream_pc_lds(const ConvPlan& p, int buf_bytes, int n_wslots);
-int conv_stream_pc_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 // 1x1 convs without a staged tile (conv_direct.hip, ConvTile::kind == 4): B fragments straight from global memory,
 // weights in registers; conv_direct_mb = cout tiles per wave, 0 when the layer is not one the kernel takes
 // conv 1x1 64 -> 256 + residual + ReLU and the conv 1x1 256 -> 64 + ReLU that reads its output, as one kernel (conv_pair.hip)

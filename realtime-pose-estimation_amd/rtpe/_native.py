@@ -13,6 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # RTPE_LIBRARY: another build of the same ABI (A/B measurements of two builds on one GPU box)
 LIB_PATH = os.environ.get("RTPE_LIBRARY") or os.path.join(_PKG_DIR, "librtpe_hip.so")
 
+ABI_VERSION = 4          # rtpe_version() of the library this binding was written against (include/rtpe_hip.h)
 RTPE_DTYPE_F16, RTPE_DTYPE_F32 = 1, 2
 OP_STEM, OP_CONV, OP_DECONV, OP_FUSE, OP_CAST, OP_AVGPOOL, OP_SE, OP_CAM_COMBINE, OP_SIGMOID_ADD = range(9)
 OP_AUX_PACK, OP_RESIZE, OP_GATE_MUL = 9, 10, 11
@@ -142,6 +143,10 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)       # AttributeError if an export is missing
             fn.restype, fn.argtypes = res, args
+        got = L.rtpe_version()
+        if got != ABI_VERSION:      # e.g. RTPE_LIBRARY pointing at a build of another round: descriptors and records differ
+            raise RuntimeError("rtpe: %s has ABI revision %d, this binding needs %d - rebuild it from this tree "
+                               "(`python -c \"import __graft_entry__ as g; g.build()\"`)" % (LIB_PATH, got, ABI_VERSION))
         _lib = L
     return _lib
 

@@ -31,7 +31,7 @@ def test_abi_exports_every_declared_symbol(built):
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(built.EXPORTS)
-    assert lib.rtpe_version() >= 1
+    assert lib.rtpe_version() == built.ABI_VERSION == 4
     assert lib.rtpe_device_count() >= 0
 
 
@@ -395,33 +395,6 @@ def test_stream_kernel_register_window_is_not_allocated(built, tmp_path):
             assert mine.search(code), "compiler-allocated register in the window: " + code.strip()
             n_window += 1
     assert n_window > 0
-    # the producer / consumer kernel (conv_stream_pc.hip) keeps its residual pieces in the same window: buffer loads into
-    # v[224:255] and the packed adds that read them are the only instructions that may name those registers
-    obj = shutil.copy(os.path.join(os.path.dirname(built.LIB_PATH), "build", "conv_stream_pc.hip.o"), str(tmp_path / "p.o"))
-    fat, co = str(tmp_path / "p.fatbin"), str(tmp_path / "p.co")
-    subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, str(tmp_path / "p2.o")], check=True)
-    subprocess.run([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                    "--input=" + fat, "--output=" + co], check=True)
-    dis = subprocess.run([llvm + "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
-    mine = re.compile(r"buffer_load_dwordx4 v\[2\d\d:2\d\d\], v\d+, s\[\d+:\d+\], s\d+ offen|v_pk_add_f16 v\d+, v\d+, v2\d\d\b")
-    n_window, in_pc = 0, False
-    for line in dis.splitlines():
-        label = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
-        if label:
-            in_pc = "conv_stream_pc_kernel" in label.group(1)
-            continue
-        if not in_pc:
-            continue
-        code = line.split("//")[0]
-        hi = 0
-        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", code):
-            hi = max(hi, int(m.group(2)))
-        for m in re.finditer(r"\bv(\d+)\b", code):
-            hi = max(hi, int(m.group(1)))
-        if hi >= 224:
-            assert mine.search(code), "compiler-allocated register in the window: " + code.strip()
-            n_window += 1
-    assert n_window > 0
 
 
 def _device_code(built, tmp_path, name):
@@ -445,7 +418,7 @@ def test_rounding_points_survive_the_compiler(built, tmp_path):
     points: the fused stem runs conv1's fp32 chain on the matrix pipe (v_mfma_f32_16x16x4_f32), neither it nor the
     64-channel kernel spills registers to scratch memory"""
     import re
-    for name in ("conv_mfma.hip", "conv_stream.hip", "conv_stream_pc.hip", "conv_block.hip", "conv_direct.hip", "conv_pair.hip",
+    for name in ("conv_mfma.hip", "conv_stream.hip", "conv_block.hip", "conv_direct.hip", "conv_pair.hip",
                  "stem_fused.hip", "conv64.hip"):
         dis = _device_code(built, tmp_path, name)
         fused = re.findall(r"v_fma_mix(?:lo|hi)_f16", dis)
@@ -651,3 +624,28 @@ def test_workspace_slot_is_per_thread():
         assert seen == [(0, 0)] and ph._WS_SLOT[0] == 2
     finally:
         assert ph.set_workspace_slot(0) == 2
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE in the environment (the form the driver uses) must run TWO ranks:
+    bench.py starts `torch.distributed.run` as a child before anything touches a GPU and passes rank 0's JSON line
+    through.  Here on the CPU: --rehearsal (control path only: process group, weight broadcast, shards, record gather,
+    barrier + max-over-ranks timing; no GPU work) over gloo."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rehearsal",
+                          "--steps", "3", "--warmup", "1", "--batch", "4"], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["config"]["records_gathered"] == 8
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["value"] is None
+    # and the single-rank form stays in this process (no child, no process group)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearsal", "--steps", "2",
+                          "--warmup", "0", "--batch", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["records_gathered"] == 3 and "starting" not in res.stderr

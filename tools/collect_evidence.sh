@@ -17,9 +17,9 @@ python tools/pmc_summary.py gpurun_out/$TAG profiles/${TAG}_pmc_summary.json > /
 python - $TAG <<'PY'
 import json, csv, sys
 tag = sys.argv[1]
-d = json.load(open('profiles/%s_bench.json' % tag)); r = d['roofline']; t = d['roofline_time_dominant']
+d = json.load(open('profiles/%s_bench.json' % tag)); r = d['roofline_secondary']; t = d['roofline']   # round 5: roofline = the time-dominant family
 print("default", d['value'], d['ms_per_step'], 'frac', r['frac'], 'launch_us', r['launch_us'], 'achieved', r['achieved'], 'phys', r['physical']['hbm_gbs_measured_traffic'], r['physical']['hbm_frac_measured_traffic'], r['physical']['mfma_frac'], r['mfma_tflops'], 'traffic', r['traffic'])
-print('time-dominant', t['frac'], t['achieved'], t['ms_per_forward'], t['share_of_forward'], 'cpu', d['cpu_baseline']['value'], 'fwd-only', d['config']['forward_only_images_per_sec_per_gpu'])
+print('build_mode', d.get('build_mode')); print('time-dominant', t['frac'], 'launch_us', t['launch_us'], 'traffic', t['traffic'], t['achieved'], t['ms_per_forward'], t['share_of_forward'], 'cpu', d['cpu_baseline']['value'], 'fwd-only', d['config']['forward_only_images_per_sec_per_gpu'])
 for f in ('bench_under_rocprof', 'bench_before_profiling', 'bench_second_run', 'bench_config1', 'bench_config4', 'bench_list_mode', 'bench_2rank_gloo_rehearsal'):
     e = json.load(open('profiles/%s_%s.json' % (tag, f))); print(f, e['value'], e['ms_per_step'], (e.get('roofline') or {}).get('launch_us'), e['config'].get('pipelined_images_per_sec'))
 rows = list(csv.DictReader(open('profiles/%s_timed_steps.csv' % tag)))

@@ -18,7 +18,8 @@ python tools/forward_profile.py 32 640 $OUT/forward_ops.txt > $OUT/forward_profi
 tail -2 $OUT/forward_ops.txt
 python bench.py --no-cpu-baseline --list tests/golden/coco_minival2017_100.txt --steps 5 --warmup 1 > $OUT/bench_list.json 2> $OUT/bench_list.err
 echo "list: $(cut -c1-160 $OUT/bench_list.json)"
-RTPE_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --no-cpu-baseline > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
+# bench.py starts its own two ranks (no WORLD_SIZE in the environment): the form the driver uses for --gpus N
+RTPE_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --no-cpu-baseline > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
 echo "2rank: $(tail -1 $OUT/bench_2rank_gloo.json | cut -c1-160)"
 for lanes in 0 2; do echo "== RTPE_LANES=$lanes"; RTPE_LANES=$lanes python tools/latency_probe.py 2>/dev/null | grep -v amdgpu; done > $OUT/latency.log
 echo "== RTPE_LANES=2 RTPE_TILE_DMA=0" >> $OUT/latency.log
