@@ -1,0 +1,521 @@
+// Fused BasicBlock for the 96-channel branch of the w48 network (pose_higher_hrnet.py:46-75):
+//     y = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )
+// in ONE kernel: the 96-channel intermediate tensor (39 MB at batch 32, 80 x 80: written by one launch of the
+// streaming kernel, read back - with its halo, by two cout blocks - by the next) never leaves the compute unit.
+// Round 5, verdict item 1: the one change that takes bytes out of the C >= 96 family instead of re-ordering them.
+//
+// Same math as conv_stream.hip (same packed weights, same k order: channel chunk 0 taps x channels, then chunk 1;
+// same rounding points: conv -> fp16, BN -> fp16, ReLU, add -> fp16), so the result is bit-identical to the two
+// launches it replaces.  Per unit = 10 x 16 output pixels of one image, all 96 channels:
+//   * the 14 x 20 x halo tile, as two 48-channel chunk buffers, LDS-DMA'd by two loader waves while the previous
+//     unit is in its second conv;
+//   * conv1 on the 12 x 18 region conv2 needs (216 pixels = 13.5 column tiles of 16), all 96 output channels in
+//     the accumulators of the four MFMA waves (wave = cout half x pixel half: 3 x 7 tiles), BN1 + ReLU -> fp16 rows of
+//     the mid tile in LDS (two 48-channel planes; zeros outside the image = conv2's padding);
+//   * conv2 on the 10 x 16 outputs from the mid tile (3 x 5 tiles per wave);
+//   * the residual is the x tile that is already in LDS: each wave takes its 8 row pieces into registers when conv1 is
+//     done, so the x buffers are free for the next unit's tile a whole conv2 before they are needed;
+//   * BN2, transposition through the (then free) mid tile, + x, ReLU, 16-byte row stores;
+//   * the weights of both convs (2 x 168 KiB) do not fit any LDS: they stream from L2 through a ring of five 12-KiB
+//     slots (2 k-steps x 96 output channels each), three groups in flight, handed over by one workgroup barrier per
+//     group; a group is requested four groups before it is multiplied.
+// LDS: ring 60 KiB + x 2 x 27.1 KiB + mid 2 x 20.25 KiB + BN parameters 1.5 KiB = 156.3 KiB, one workgroup per CU.
+#include "conv_stream_dev.h"
+
+namespace rtpe {
+namespace {
+
+constexpr int kBTH = 10, kBTW = 16;                    // output tile
+constexpr int kBMH = kBTH + 2, kBMW = kBTW + 2;        // conv1 region = mid tile (12 x 18)
+constexpr int kBXH = kBTH + 4, kBXW = kBTW + 4;        // x halo tile (14 x 20)
+constexpr int kBPS = 96;                               // LDS bytes per pixel of a 48-channel chunk
+// x row pitch: a 16-pixel column tile of conv1 walks the 18-wide region and wraps to the next x row; the wrap keeps the
+// bank pattern of consecutive pixels when pitch == 18 * 96 (mod 256): 1,920 -> 1,984
+constexpr int kBXPitch = 1984;
+constexpr int kBXBytes = kBXH * kBXPitch;              // 27,776 B per chunk
+constexpr int kBMPitch = kBMW * kBPS;                  // 1,728: a conv2 column tile is one output row, no wrap
+constexpr int kBMidPlane = kBMH * kBMPitch;            // 20,736 B per 48-channel plane
+constexpr int kBNT1 = 7, kBNT2 = 5;                    // column tiles per wave: conv1 (2 x 7 = 14 for 13.5), conv2 (2 x 5)
+constexpr int kBGroup = 2;                             // k-steps per ring slot
+constexpr int kBSlot = kBGroup * 6 * 1024;             // 12 KiB: 2 k-steps x 6 cout tiles
+constexpr int kBRing = 5;
+constexpr int kBGroupsPerConv = 14, kBGroupsPerUnit = 28;
+constexpr int kBDmaPerGroup = kBGroup * 6;             // 1-KiB LDS-DMA instructions per group
+constexpr int kBRowB = 3 * 32 + 16;                    // transposed output row of a wave's 48 channels
+constexpr int kBNIT = 8;                               // 16-byte row pieces per lane in epilogue B (80 pixels x 6 / 64 = 7.5)
+constexpr int kBOffRing = 0;
+constexpr int kBOffX = kBRing * kBSlot;
+constexpr int kBOffMid = kBOffX + 2 * kBXBytes;
+constexpr int kBOffBn = kBOffMid + 2 * kBMidPlane;
+constexpr int kBLds = kBOffBn + 2 * 2 * 96 * 4;
+static_assert(kBLds <= 160 * 1024, "fused 96-channel block: LDS budget");
+static_assert(4 * 80 * kBRowB <= 2 * kBMidPlane, "output slabs overlay the mid tile");
+constexpr int kBWaves = 4, kBLoad = 3;
+
+// profiling ablations exist in -DRTPE_DIAG builds only (wrong results by construction)
+#ifdef RTPE_DIAG
+#define RTPE_B96_ABL(a, bit) ((a).ablate & (bit))
+#define RTPE_B96_MFMA(A, B, C) ((a.ablate & 1) ? (C) : __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0))
+#else
+#define RTPE_B96_ABL(a, bit) 0
+#define RTPE_B96_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+#endif
+
+}  // namespace
+
+struct Block96Args {
+  const _Float16* x;
+  _Float16* y;
+  const _Float16* w1;        // packed fragments [2 cout blocks][2 channel chunks][14 k-steps][3][64 lanes][16 B]
+  const _Float16* w2;
+  const float* ab1;          // alpha[96], beta[96]
+  const float* ab2;
+  int N, H, W, in_ld, out_ld;
+  long long in_cs, out_cs;   // element offset of 48-channel chunk 1 from chunk 0 (48 = NHWC; N*H*W*48 = plane-major)
+  int tiles_x, tiles_y;
+  FastDiv div_tiles_x, div_tiles_xy;
+  int x_bytes;
+  unsigned long long* dbg;   // -DRTPE_CONV_STAMPS builds only: per-phase cycle sums (16 slots)
+  int ablate;                // -DRTPE_DIAG builds only (RTPE_BLOCK96_ABL): 1 no k loops, 2 no epilogue A, 4 no output stores,
+                             // 8 no x-tile requests, 16 no weight requests - wrong results, timing only
+};
+
+__global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(const Block96Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem + kBOffRing;
+  char* const xt = smem + kBOffX;
+  char* const mid = smem + kBOffMid;
+  float* const bnp = reinterpret_cast<float*>(smem + kBOffBn);     // [conv][alpha | beta][96]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD x (= blockIdx % 8) owns a contiguous eighth of the row-major tile list, its G workgroups walk it with stride G
+  // (as conv_block.hip): tiles that share halo rows are multiplied on one XCD at about the same time
+  const int n_tiles = a.N * a.tiles_x * a.tiles_y;
+  const int G = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jw = (int)(blockIdx.x >> 3);
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd;
+  const int tiles_xcd = min(per_xcd, n_tiles - t_begin);
+  const int U = jw < tiles_xcd ? (tiles_xcd - jw + G - 1) / G : 0;
+  if (U == 0) return;
+  const uint32_t tiles_xy = (uint32_t)(a.tiles_x * a.tiles_y);
+  auto unit_origin = [&](int u, uint32_t* n, int* py0, int* px0) __attribute__((always_inline)) {
+    uint32_t t = (uint32_t)(t_begin + jw + u * G);
+    *n = fdiv(t, a.div_tiles_xy);
+    t -= *n * tiles_xy;
+    const uint32_t tyi = fdiv(t, a.div_tiles_x);
+    *py0 = (int)tyi * kBTH;
+    *px0 = (int)(t - tyi * a.tiles_x) * kBTW;
+  };
+
+  if (wv == kBWaves) {
+    // ----------------------------- weight loader -----------------------------
+    // group q = 28 u + gq: gq < 14 -> conv1, else conv2; k-steps 2 g, 2 g + 1 of the conv (g = gq % 14), chunk g / 7;
+    // slot q % 5 = [k-step of the group][cout block][3 tiles] x 1 KiB.  Before barrier B(q) the groups <= q + 1 have
+    // landed; behind it the slot of group q - 1 is free and takes group q + 4.
+    __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w1), 0, 2 * 2 * 14 * 3 * 1024, 0x00020000);
+    __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w2), 0, 2 * 2 * 14 * 3 * 1024, 0x00020000);
+    const int voff = lane * 16;
+    const int Q = kBGroupsPerUnit * U;
+    int gq_i = 0, slot_i = 0;                            // group-in-unit and ring slot of the next group to issue
+    auto issue = [&]() __attribute__((always_inline)) {
+      const int conv2 = gq_i >= kBGroupsPerConv;
+      const int g = conv2 ? gq_i - kBGroupsPerConv : gq_i;
+      const int cc = g >= 7;
+      const int k0 = 2 * g - 14 * cc;
+      char* dst = ring + slot_i * kBSlot;
+      if (!RTPE_B96_ABL(a, 16)) {
+#pragma unroll
+        for (int kk = 0; kk < kBGroup; ++kk)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int src = (((cb * 2 + cc) * 14) + k0 + kk) * 3 * 1024;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              if (conv2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(dst + (kk * 6 + cb * 3 + m) * 1024), 16, voff, src + m * 1024, 0, 0);
+              else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(dst + (kk * 6 + cb * 3 + m) * 1024), 16, voff, src + m * 1024, 0, 0);
+            }
+          }
+      }
+      gq_i = gq_i + 1 == kBGroupsPerUnit ? 0 : gq_i + 1;
+      slot_i = slot_i + 1 == kBRing ? 0 : slot_i + 1;
+    };
+    for (int q = 0; q < 4 && q < Q; ++q) issue();
+    int gq = 0;
+#ifdef RTPE_CONV_STAMPS
+    unsigned long long w0, w1, w2, w3, wwait = 0, wbar = 0, wissue = 0;
+#endif
+    for (int q = 0; q < Q; ++q) {
+      SSTAMP(w0);
+      // groups issued so far: <= q + 3; allowed in flight: q + 2, q + 3
+      if (q + 3 < Q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kBDmaPerGroup) : "memory");
+      else if (q + 2 < Q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBDmaPerGroup) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SSTAMP(w1);
+      RTPE_SBARRIER();                                   // B(q)
+      SSTAMP(w2);
+      if (q + 4 < Q) issue();
+      SSTAMP(w3);
+#ifdef RTPE_CONV_STAMPS
+      wwait += w1 - w0; wbar += w2 - w1; wissue += w3 - w2;
+#endif
+      if (++gq == kBGroupsPerUnit) {
+        gq = 0;
+        RTPE_SBARRIER();                                 // E2 of the unit
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RTPE_CONV_STAMPS
+    if (a.dbg != nullptr && lane == 0) { atomicAdd(&a.dbg[8], wwait); atomicAdd(&a.dbg[9], wbar); atomicAdd(&a.dbg[10], wissue); atomicAdd(&a.dbg[11], (unsigned long long)Q); }
+#endif
+    return;
+  }
+
+  if (wv > kBWaves) {
+    // ------------------------------ tile loaders ------------------------------
+    const int jl = wv - kBWaves - 1;                     // rows [0,7) or [7,14) of both chunk buffers
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, a.x_bytes, 0x00020000);
+    constexpr int rowslots = kBXW * 6;                   // 120 16-byte slots per halo row and chunk
+    auto issue = [&](int u) __attribute__((always_inline)) {
+      uint32_t n;
+      int py0, px0;
+      unit_origin(u, &n, &py0, &px0);
+      const int iy0 = py0 - 2, ix0 = px0 - 2;
+      uint32_t voff[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int q = k * 64 + lane;
+        const int hx = q / 6, sl = q - hx * 6;
+        const int ix = ix0 + hx;
+        voff[k] = (q < rowslots && (unsigned)ix < (unsigned)a.W) ? (uint32_t)(ix * a.in_ld + sl * 8) * 2u : 0x80000000u;
+      }
+      const int img_row0 = (int)n * a.H;
+      if (RTPE_B96_ABL(a, 8)) return;
+      for (int cc = 0; cc < 2; ++cc) {
+        char* buf = xt + cc * kBXBytes;
+        const int coff = (int)(cc * a.in_cs) * 2;
+        for (int r = jl * (kBXH / 2); r < (jl + 1) * (kBXH / 2); ++r) {
+          const int iy = iy0 + r;
+          const bool row_ok = (unsigned)iy < (unsigned)a.H;
+          const int soff = row_ok ? (img_row0 + iy) * a.W * a.in_ld * 2 + coff : 0;
+          char* dst = buf + r * kBXPitch;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, (int)(row_ok ? voff[0] : 0x80000000u), soff, 0, 0);
+          if (lane < rowslots - 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + 1024), 16, (int)(row_ok ? voff[1] : 0x80000000u), soff, 0, 0);
+        }
+      }
+    };
+    issue(0);
+#ifdef RTPE_CONV_STAMPS
+    unsigned long long t0, t1, twait = 0;
+#endif
+    for (int u = 0; u < U; ++u) {
+      SSTAMP(t0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this loader's rows of tile u have landed
+      SSTAMP(t1);
+#ifdef RTPE_CONV_STAMPS
+      twait += t1 - t0;
+#endif
+      for (int b = 0; b < kBGroupsPerConv; ++b) RTPE_SBARRIER();          // B(0) .. B(13): conv1
+      RTPE_SBARRIER();                                   // B(14): conv1 is done with the x tile, the residual is in registers
+      if (u + 1 < U) issue(u + 1);
+      for (int b = kBGroupsPerConv + 1; b < kBGroupsPerUnit; ++b) RTPE_SBARRIER();   // B(15) .. B(27)
+      RTPE_SBARRIER();                                   // E2
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RTPE_CONV_STAMPS
+    if (a.dbg != nullptr && lane == 0) atomicAdd(&a.dbg[12], twait);
+#endif
+    return;
+  }
+
+  // -------------------------------- MFMA waves --------------------------------
+  const int r = lane & 15, g = lane >> 4;
+  const int hc = wv & 1;                                 // cout half (and the mid plane / residual chunk of this wave)
+  const int hq = wv >> 1;                                // pixel half
+  // BN parameters of both convs -> LDS (read back per epilogue: 48 registers would otherwise live through the k loops)
+  for (int i = tid; i < 2 * 2 * 96; i += kBWaves * 64) {
+    const int c = i / 192, j = i - c * 192;
+    bnp[i] = (c ? a.ab2 : a.ab1)[j];
+  }
+  // byte offset of this lane group's 8 channels in k-step k of a chunk: conv1 walks an x chunk buffer, conv2 a mid plane
+  int toff1[14], toff2[14];
+#pragma unroll
+  for (int k = 0; k < 14; ++k) {
+    int kk = k * 32 + g * 8;
+    if (kk >= 9 * 48) kk -= 9 * 48;                      // zero-weight k padding: any finite in-tile data
+    const int tap = kk / 48, c = kk - tap * 48;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    toff1[k] = ty * kBXPitch + tx * kBPS + c * 2;
+    toff2[k] = ty * kBMPitch + tx * kBPS + c * 2;
+  }
+  int pix1[kBNT1], pix2[kBNT2];
+#pragma unroll
+  for (int nt = 0; nt < kBNT1; ++nt) {
+    int p = (hq * kBNT1 + nt) * 16 + r;
+    p = p < kBMH * kBMW ? p : kBMH * kBMW - 1;           // idle slots recompute the last pixel
+    const int my = p / kBMW, mx = p - my * kBMW;
+    pix1[nt] = my * kBXPitch + mx * kBPS;
+  }
+#pragma unroll
+  for (int nt = 0; nt < kBNT2; ++nt) pix2[nt] = (hq * kBNT2 + nt) * kBMPitch + r * kBPS;
+  // epilogue B, 16-byte row piece `it` of this lane: where it is in the wave's transposed slab (eoff), in the x chunk
+  // buffer of this wave's channel half (xoff: the residual), and its position in the output tile
+  int eoff[kBNIT], xoff[kBNIT], epos[kBNIT];
+#pragma unroll
+  for (int it = 0; it < kBNIT; ++it) {
+    int c = it * 64 + lane;
+    const bool exists = c < kBNT2 * 16 * 6;
+    c = exists ? c : 0;
+    const int pw = c / 6, slot = c - pw * 6;
+    const int oy = hq * kBNT2 + (pw >> 4), ox = pw & 15;
+    eoff[it] = pw * kBRowB + slot * 16;
+    xoff[it] = (oy + 2) * kBXPitch + (ox + 2) * kBPS + slot * 16;
+    epos[it] = ((exists ? oy : 0x7fff) << 16) | (ox << 8) | (slot * 16);
+  }
+  const char* const xres = xt + hc * kBXBytes;
+  char* const midw = mid + hc * kBMidPlane;              // epilogue A writes this wave's 48 channels: plane hc
+  char* const obuf = mid + wv * (kBNT2 * 16 * kBRowB);
+  const char* const ringl = ring + lane * 16 + hc * 3 * 1024;
+  int slot = 0;                                          // ring slot of the next group (q % 5)
+
+  // One chunk pass = 14 k-steps = 7 groups of the ring, fully unrolled.  A fragments: double-buffered, read one k-step
+  // ahead (the barrier of a group guarantees the NEXT group too, so the look-ahead may cross a group).  B fragments: ONE
+  // register set - a fragment is re-read for the next k-step right after the three MFMAs that use it.  FIRST: the pass
+  // starts cold (its operands are read behind its first barrier); NEXT: the last k-step reads the first operands of the
+  // pass that follows (bnext; same tap table).
+  auto chunk_pass = [&](auto& acc, half8 (&af)[2][3], auto& bf, const char* bcur, const char* bnext, const auto& pix,
+                        const int (&toff)[14], auto first_c, auto next_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value, NEXT = decltype(next_c)::value;
+    constexpr int NT = sizeof(bf) / sizeof(bf[0]);
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int cur = k & 1, nxt = cur ^ 1;
+      if ((k & 1) == 0) {
+        RTPE_SBARRIER();                                 // B(q): this group and the next one are in the ring
+        if (FIRST && k == 0) {
+          const char* wl = ringl + slot * kBSlot;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) af[0][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const half8*>(bcur + pix[nt] + toff[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr bool kMoreAlways = NEXT;
+      const bool more = k + 1 < 14 || kMoreAlways;
+      if (more) {
+        // A fragments of k-step k + 1: the other half of this slot, or the first half of the next slot
+        int s = slot;
+        if (k & 1) s = s + 1 == kBRing ? 0 : s + 1;
+        const char* wl = ringl + s * kBSlot + ((k & 1) ? 0 : 6 * 1024);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) af[nxt][m] = *reinterpret_cast<const half8*>(wl + m * 1024);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+          acc[m][nt] = RTPE_B96_MFMA(af[cur][m], bf[nt], acc[m][nt]);
+        if (k + 1 < 14) bf[nt] = *reinterpret_cast<const half8*>(bcur + pix[nt] + toff[k + 1 < 14 ? k + 1 : 0]);
+        else if (NEXT) bf[nt] = *reinterpret_cast<const half8*>(bnext + pix[nt] + toff[0]);
+      }
+      // issue order inside the k-step: three MFMAs of a column tile, then the re-read of that tile's B fragment for the
+      // next k-step (and, behind the first three tiles, one A fragment of the next k-step each): every read has at least
+      // 3 * (NT - 1) MFMAs between its issue and its first use, and the matrix pipe never waits for a burst of reads
+      if (more) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                       // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                       // VALU (addresses)
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                       // DS read: B of this tile, one A fragment
+        }
+#pragma unroll
+        for (int nt = 3; nt < NT; ++nt) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (k & 1) slot = slot + 1 == kBRing ? 0 : slot + 1;
+    }
+  };
+
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long st[8] = {0}, m0, m1, m2, m3, m4, m5, m6, m7;
+  const unsigned long long k_begin = __builtin_readcyclecounter();
+#endif
+  for (int u = 0; u < U; ++u) {
+    uint32_t n;
+    int py0, px0;
+    unit_origin(u, &n, &py0, &px0);
+    half8 af[2][3];
+    SSTAMP(m0);
+
+    // ------------------------------- conv1 -------------------------------
+    float4v acc1[3][kBNT1];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kBNT1; ++nt) acc1[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    {
+      half8 bf[kBNT1];
+      chunk_pass(acc1, af, bf, xt, xt + kBXBytes, pix1, toff1, std::true_type(), std::true_type());
+      SSTAMP(m1);
+      chunk_pass(acc1, af, bf, xt + kBXBytes, xt, pix1, toff1, std::false_type(), std::false_type());
+    }
+    SSTAMP(m2);
+    // the residual: this wave's row pieces of the block input, out of the x tile before it is released
+    half8 rv[kBNIT];
+#pragma unroll
+    for (int it = 0; it < kBNIT; ++it) rv[it] = *reinterpret_cast<const half8*>(xres + xoff[it]);
+    // ---- epilogue A: BN1 + ReLU -> fp16 rows of the mid tile (the unfused path's HBM tensor) ----
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int re = lane_e & 15, ge = lane_e >> 4;
+      float4v al[3], be[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        al[m] = *reinterpret_cast<const float4v*>(bnp + (hc * 3 + m) * 16 + ge * 4);
+        be[m] = *reinterpret_cast<const float4v*>(bnp + 96 + (hc * 3 + m) * 16 + ge * 4);
+      }
+      if (!RTPE_B96_ABL(a, 2)) {
+#pragma unroll
+        for (int nt = 0; nt < kBNT1; ++nt) {
+          const int p = (hq * kBNT1 + nt) * 16 + re;
+          const int my = p / kBMW, mx = p - my * kBMW;
+          const int iy = py0 - 1 + my, ix = px0 - 1 + mx;
+          const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const half4 o_bn = bn_round(acc1[m][nt], al[m], be[m]);
+            typedef short short4v __attribute__((ext_vector_type(4)));
+            short4v b = __builtin_bit_cast(short4v, o_bn);
+            b = b & ~(b >> 15);                          // ReLU on the sign bits
+            if (!inside) b = b ^ b;                      // conv2's zero padding
+            if (p < kBMH * kBMW) *reinterpret_cast<short4v*>(midw + p * kBPS + m * 32 + ge * 8) = b;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // mid rows written, residual pieces read: the x tile is free
+    }
+
+    // ------------------------------- conv2 -------------------------------
+    float4v acc2[3][kBNT2];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int nt = 0; nt < kBNT2; ++nt) acc2[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    {
+      half8 bf[kBNT2];
+      SSTAMP(m3);
+      chunk_pass(acc2, af, bf, mid, mid + kBMidPlane, pix2, toff2, std::true_type(), std::true_type());
+      SSTAMP(m4);
+      chunk_pass(acc2, af, bf, mid + kBMidPlane, mid, pix2, toff2, std::false_type(), std::false_type());
+    }
+    SSTAMP(m5);
+    // ---- epilogue B: BN2, transposed through the (now free) mid tile, + x, ReLU, store ----
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int re = lane_e & 15, ge = lane_e >> 4;
+      float4v al[3], be[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        al[m] = *reinterpret_cast<const float4v*>(bnp + 192 + (hc * 3 + m) * 16 + ge * 4);
+        be[m] = *reinterpret_cast<const float4v*>(bnp + 192 + 96 + (hc * 3 + m) * 16 + ge * 4);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RTPE_SBARRIER();                                   // E2: every wave is done reading the mid tile
+      SSTAMP(m6);
+#pragma unroll
+      for (int nt = 0; nt < kBNT2; ++nt)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const half4 o_bn = bn_round(acc2[m][nt], al[m], be[m]);
+          *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kBRowB + m * 32 + ge * 8) = o_bn;
+        }
+      half8 ov[kBNIT];
+#pragma unroll
+      for (int it = 0; it < kBNIT; ++it) ov[it] = *reinterpret_cast<const half8*>(obuf + eoff[it]);
+      const int hy = a.H - py0, hx = a.W - px0;
+      char* const yb = reinterpret_cast<char*>(a.y + (((size_t)n * a.H + py0) * a.W + px0) * a.out_ld + (size_t)hc * a.out_cs);
+      const uint32_t ld2 = (uint32_t)a.out_ld * 2u, row_pix = (uint32_t)a.W & 0xffffffu;
+#pragma unroll
+      for (int it = 0; it < kBNIT; ++it) {
+        int e = epos[it];
+        asm volatile("" : "+v"(e));                      // lane-only math must not be hoisted out of the unit loop
+        half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
+        short8 b = __builtin_bit_cast(short8, v);
+        b = b & ~(b >> 15);
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx && !RTPE_B96_ABL(a, 4)) {
+          const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
+          store16_wt(yb + __umul24(pix, ld2) + ((uint32_t)e & 255u), b);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is read: the next unit's epilogue A may overwrite it
+    }
+#ifdef RTPE_CONV_STAMPS
+    SSTAMP(m7);
+    st[0] += m1 - m0; st[1] += m2 - m1; st[2] += m3 - m2; st[3] += m4 - m3; st[4] += m5 - m4; st[5] += m6 - m5; st[6] += m7 - m6; st[7] += 1;
+#endif
+  }
+#ifdef RTPE_CONV_STAMPS
+  if (a.dbg != nullptr && lane == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], st[i]);
+    atomicAdd(&a.dbg[13], __builtin_readcyclecounter() - k_begin);
+  }
+#endif
+}
+
+// any map runs (partial 10 x 16 tiles are masked); it PAYS where the tiling wastes less than ~40 % of the pixel slots -
+// smaller or narrower maps are faster on two launches of the streaming kernel (the executor asks conv_block96_pays)
+bool conv_block96_supports(int H, int W) { return H >= 1 && W >= 1 && H <= 0x7ffe && W <= 0xffffff; }
+bool conv_block96_pays(int H, int W) {
+  if (!conv_block96_supports(H, W) || H < 5 || W < 8) return false;
+  const double slots = (double)((H + kBTH - 1) / kBTH * kBTH) * ((W + kBTW - 1) / kBTW * kBTW);
+  return (double)H * W >= 0.6 * slots;
+}
+
+int conv_block96_launch(const _Float16* x, int in_ld, long long in_cs, size_t x_bytes, _Float16* y, int out_ld, long long out_cs,
+                        const _Float16* w1, const float* ab1, const _Float16* w2, const float* ab2, int N, int H, int W,
+                        hipStream_t s, unsigned long long* dbg) {
+  RTPE_REQUIRE(x && y && w1 && w2 && ab1 && ab2 && N > 0, "basic block (96): null argument");
+  RTPE_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= 48 && out_ld >= 48 && in_cs % 8 == 0 && out_cs % 8 == 0 &&
+                   (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+               "basic block (96): views must be 16-byte aligned (in_ld=%d out_ld=%d)", in_ld, out_ld);
+  RTPE_REQUIRE((in_ld >= 96 && in_cs == 48) || (in_ld == 48 && in_cs >= 48), "basic block (96): in_ld=%d chunk stride %lld", in_ld, in_cs);
+  RTPE_REQUIRE((out_ld >= 96 && out_cs == 48) || (out_ld == 48 && out_cs >= 48), "basic block (96): out_ld=%d chunk stride %lld", out_ld, out_cs);
+  RTPE_REQUIRE(x_bytes > 0 && x_bytes < 0x80000000ull, "basic block (96): input view of %zu bytes", x_bytes);
+  RTPE_REQUIRE(H <= 0x7ffe && W <= 0xffffff, "basic block (96): map %d x %d", H, W);
+  static unsigned long long attr_mask = 0;
+  if (first_use_on_device(&attr_mask))
+    RTPE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block96_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  Block96Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.ab1 = ab1; a.ab2 = ab2;
+  a.N = N; a.H = H; a.W = W; a.in_ld = in_ld; a.out_ld = out_ld; a.in_cs = in_cs; a.out_cs = out_cs;
+  a.tiles_x = (W + kBTW - 1) / kBTW;
+  a.tiles_y = (H + kBTH - 1) / kBTH;
+  a.div_tiles_x = make_fastdiv(a.tiles_x);
+  a.div_tiles_xy = make_fastdiv(a.tiles_x * a.tiles_y);
+  a.x_bytes = (int)x_bytes;
+  a.dbg = dbg;
+  static const int abl = RTPE_DIAG_ENV_INT("RTPE_BLOCK96_ABL", 0);
+  a.ablate = abl;
+  const long tiles = (long)N * a.tiles_x * a.tiles_y;
+  static const int g_env = env_int("RTPE_PERSIST_G", 32);
+  long G = g_env;                                         // one workgroup per CU
+  if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
+  hipLaunchKernelGGL(conv_block96_kernel, dim3((unsigned)(8 * G)), dim3((kBWaves + kBLoad) * 64), kBLds, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+}  // namespace rtpe

@@ -22,24 +22,25 @@ DEFAULT = ["48,48,3,1,160,160,32,1", "96,96,3,1,80,80,32,1", "192,192,3,1,40,40,
 
 
 def run_block(case, reps=3):
-    """case = block,H,W,N : the fused BasicBlock kernel (rtpe_basicblock_nhwc)"""
-    _, H, W, N = case.split(",")
+    """case = block,H,W,N : the fused BasicBlock kernel (rtpe_basicblock_nhwc); block96,H,W,N : the 96-channel one"""
+    kind, H, W, N = case.split(",")
     H, W, N = int(H), int(W), int(N)
+    C = 96 if kind == "block96" else 48
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(N, H, W, 48, generator=g).half().to(dev)
-    ws = [((torch.rand(48, 48, 3, 3, generator=g) * 2 - 1) / (48 * 9) ** 0.5).half().contiguous().numpy() for _ in range(2)]
-    a = np.ones(48, np.float32)
-    b = np.zeros(48, np.float32)
+    x = torch.randn(N, H, W, C, generator=g).half().to(dev)
+    ws = [((torch.rand(C, C, 3, 3, generator=g) * 2 - 1) / (C * 9) ** 0.5).half().contiguous().numpy() for _ in range(2)]
+    a = np.ones(C, np.float32)
+    b = np.zeros(C, np.float32)
     y = torch.empty_like(x)
     fp = ctypes.POINTER(ctypes.c_float)
     ts = []
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nat.check(nat.lib().rtpe_basicblock_nhwc(x.data_ptr(), N, H, W, ws[0].ctypes.data, a.ctypes.data_as(fp),
-                                                 b.ctypes.data_as(fp), ws[1].ctypes.data, a.ctypes.data_as(fp),
-                                                 b.ctypes.data_as(fp), y.data_ptr(), nat.stream_ptr(dev)))
+        nat.check(nat.lib().rtpe_basicblock_nhwc_ex(x.data_ptr(), N, H, W, C, ws[0].ctypes.data, a.ctypes.data_as(fp),
+                                                    b.ctypes.data_as(fp), ws[1].ctypes.data, a.ctypes.data_as(fp),
+                                                    b.ctypes.data_as(fp), y.data_ptr(), nat.stream_ptr(dev)))
         ts.append(time.perf_counter() - t0)
     print("%-28s host-inclusive best %.1f us" % (case, min(ts) * 1e6), flush=True)
 
