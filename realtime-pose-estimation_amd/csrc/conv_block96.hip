@@ -47,10 +47,12 @@ constexpr int kBOffRing = 0;
 constexpr int kBOffX = kBRing * kBSlot;
 constexpr int kBOffMid = kBOffX + 2 * kBXBytes;
 constexpr int kBOffBn = kBOffMid + 2 * kBMidPlane;
-constexpr int kBLds = kBOffBn + 2 * 2 * 96 * 4;
+constexpr int kBOffFlags = kBOffBn + 2 * 2 * 96 * 4;
+constexpr int kBLds = kBOffFlags + 128;
+constexpr int kBSNIT = 15;                             // 16-byte row pieces per lane of a store wave (80 pixels x 12 / 64)
 static_assert(kBLds <= 160 * 1024, "fused 96-channel block: LDS budget");
 static_assert(4 * 80 * kBRowB <= 2 * kBMidPlane, "output slabs overlay the mid tile");
-constexpr int kBWaves = 4, kBLoad = 3;
+constexpr int kBWaves = 4, kBLoad = 4;               // 4 MFMA waves, 2 weight loaders, 2 tile + store waves
 
 // profiling ablations exist in -DRTPE_DIAG builds only (wrong results by construction)
 #ifdef RTPE_DIAG
@@ -80,12 +82,77 @@ struct Block96Args {
                              // 8 no x-tile requests, 16 no weight requests - wrong results, timing only
 };
 
-__global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(const Block96Args a) {
+// ---- hand-over words in LDS (all monotonic counters; LDS executes one wave's operations in order, so a counter written
+// after a wave's reads / writes of a buffer is seen by others only after those have been executed) -------------------
+constexpr int kFWl = 0;        // [2]  weight loader cb: groups of its cout block that have landed in the ring
+constexpr int kFProg = 4;      // [4]  MFMA wave w: ring groups it is done reading (16-byte aligned: one ds_read_b128)
+constexpr int kFXl = 8;        // [2]  tile wave jl: x tiles (units) whose rows have landed
+constexpr int kFMid = 12;      // [4]  MFMA wave w: units whose mid rows it has written
+constexpr int kFSlabR = 16;    // [4]  MFMA wave w: units whose output slab it has written
+constexpr int kFSlabD = 20;    // [2]  tile wave jl: units whose slab rows it has read
+constexpr int kFWords = 32;
+
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+// the hand-over words are accessed through LDS-address-space pointers: a generic `volatile` pointer compiles to
+// flat_load / flat_store ... sc0 sc1 with a full vmcnt(0) + lgkmcnt(0) drain per access (measured: the k loops 60 % slower)
+typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;
+typedef volatile __attribute__((address_space(3))) uint4v lds_flag4_t;
+typedef volatile __attribute__((address_space(3))) uint2v lds_flag2_t;
+
+__device__ __forceinline__ uint32_t flag_min4(lds_flag_t* f) {
+  const uint4v v = *(lds_flag4_t*)f;
+  const uint32_t m = min(min(v[0], v[1]), min(v[2], v[3]));
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+}
+__device__ __forceinline__ uint32_t flag_min2(lds_flag_t* f) {
+  const uint2v v = *(lds_flag2_t*)f;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)min(v[0], v[1]));
+}
+// one lane publishes; the "memory" clobbers keep the compiler from moving LDS accesses across the publication
+__device__ __forceinline__ void flag_set(lds_flag_t* f, uint32_t v, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) *f = v;
+  asm volatile("" ::: "memory");
+}
+// Every wait is BOUNDED: a hand-over that never comes (a protocol error) ends the wait after ~2^21 polls (tens of
+// milliseconds) with a mark in the last flag word instead of hanging the GPU; the results are then wrong and the
+// launch reports nothing - the parity tests are what catches that.
+constexpr int kSpinCap = 1 << 21;
+#ifndef RTPE_B96_SLEEP_W
+#define RTPE_B96_SLEEP_W 1
+#endif
+#ifndef RTPE_B96_SLEEP_S
+#define RTPE_B96_SLEEP_S 12
+#endif
+constexpr int kSleepW = RTPE_B96_SLEEP_W, kSleepS = RTPE_B96_SLEEP_S;   // weight loaders / tile + store waves
+// SLEEP: 64-cycle units between two polls of a helper wave (a poll costs the MFMA wave on its SIMD ~10 issue slots)
+template <int SLEEP>
+__device__ __forceinline__ void wait_min4(lds_flag_t* f, uint32_t need, lds_flag_t* err) {
+  int spins = 0;
+  while (flag_min4(f) < need) {
+    if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+    if (++spins > kSpinCap || ((spins & 1023) == 0 && *err != 0u)) { *err = 0xdead0004u; break; }
+  }
+  asm volatile("" ::: "memory");
+}
+template <int SLEEP>
+__device__ __forceinline__ void wait_min2(lds_flag_t* f, uint32_t need, lds_flag_t* err) {
+  int spins = 0;
+  while (flag_min2(f) < need) {
+    if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+    if (++spins > kSpinCap || ((spins & 1023) == 0 && *err != 0u)) { *err = 0xdead0002u; break; }
+  }
+  asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(512) conv_block96_kernel(const Block96Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem + kBOffRing;
   char* const xt = smem + kBOffX;
   char* const mid = smem + kBOffMid;
   float* const bnp = reinterpret_cast<float*>(smem + kBOffBn);     // [conv][alpha | beta][96]
+  lds_flag_t* const flg = (lds_flag_t*)(smem + kBOffFlags);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,75 +175,84 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
     *py0 = (int)tyi * kBTH;
     *px0 = (int)(t - tyi * a.tiles_x) * kBTW;
   };
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long k_start;
+  SSTAMP(k_start);
+#endif
+  // BN parameters of both convs and the hand-over words -> LDS; the ONLY workgroup barrier of the kernel
+  for (int i = tid; i < 2 * 2 * 96; i += 512) {
+    const int c = i / 192, j = i - c * 192;
+    bnp[i] = (c ? a.ab2 : a.ab1)[j];
+  }
+  if (tid < kFWords) flg[tid] = 0u;
+  __syncthreads();
 
-  if (wv == kBWaves) {
-    // ----------------------------- weight loader -----------------------------
-    // group q = 28 u + gq: gq < 14 -> conv1, else conv2; k-steps 2 g, 2 g + 1 of the conv (g = gq % 14), chunk g / 7;
-    // slot q % 5 = [k-step of the group][cout block][3 tiles] x 1 KiB.  Before barrier B(q) the groups <= q + 1 have
-    // landed; behind it the slot of group q - 1 is free and takes group q + 4.
+  if (wv == 4 || wv == 5) {
+    // ----------------------------- weight loaders -----------------------------
+    // loader cb streams the fragments of cout block cb: group j (a global count over the units; j % 28 < 14 -> conv1, else
+    // conv2; k-steps 2 g, 2 g + 1 of the conv, chunk g / 7) goes to ring slot j % 5, bytes [k-step][cb][3 tiles] x 1 KiB.
+    // The slot held group j - 5: free once every MFMA wave has counted j - 4 groups.  Two groups in flight behind the
+    // published count.
+    const int cb = wv - 4;
     __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w1), 0, 2 * 2 * 14 * 3 * 1024, 0x00020000);
     __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.w2), 0, 2 * 2 * 14 * 3 * 1024, 0x00020000);
     const int voff = lane * 16;
     const int Q = kBGroupsPerUnit * U;
-    int gq_i = 0, slot_i = 0;                            // group-in-unit and ring slot of the next group to issue
-    auto issue = [&]() __attribute__((always_inline)) {
-      const int conv2 = gq_i >= kBGroupsPerConv;
-      const int g = conv2 ? gq_i - kBGroupsPerConv : gq_i;
-      const int cc = g >= 7;
-      const int k0 = 2 * g - 14 * cc;
-      char* dst = ring + slot_i * kBSlot;
-      if (!RTPE_B96_ABL(a, 16)) {
+    int gq = 0, slot_i = 0;
+#ifdef RTPE_CONV_STAMPS
+    unsigned long long w0, w1, w2, w3, wpoll = 0, wissue = 0, wwait = 0;
+#endif
+    for (int j = 0; j < Q; ++j) {
+      SSTAMP(w0);
+      if (j >= kBRing) wait_min4<kSleepW>(flg + kFProg, (uint32_t)(j - kBRing + 1), flg + kFWords - 1);
+      SSTAMP(w1);
+      {
+        const int conv2 = gq >= kBGroupsPerConv;
+        const int g = conv2 ? gq - kBGroupsPerConv : gq;
+        const int cc = g >= 7;
+        const int k0 = 2 * g - 14 * cc;
+        char* dst = ring + slot_i * kBSlot + cb * 3 * 1024;
+        if (!RTPE_B96_ABL(a, 16)) {
 #pragma unroll
-        for (int kk = 0; kk < kBGroup; ++kk)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
+          for (int kk = 0; kk < kBGroup; ++kk) {
             const int src = (((cb * 2 + cc) * 14) + k0 + kk) * 3 * 1024;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
               if (conv2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(dst + (kk * 6 + cb * 3 + m) * 1024), 16, voff, src + m * 1024, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(dst + (kk * 6 + m) * 1024), 16, voff, src + m * 1024, 0, 0);
               else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(dst + (kk * 6 + cb * 3 + m) * 1024), 16, voff, src + m * 1024, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(dst + (kk * 6 + m) * 1024), 16, voff, src + m * 1024, 0, 0);
             }
           }
+        }
+        gq = gq + 1 == kBGroupsPerUnit ? 0 : gq + 1;
+        slot_i = slot_i + 1 == kBRing ? 0 : slot_i + 1;
       }
-      gq_i = gq_i + 1 == kBGroupsPerUnit ? 0 : gq_i + 1;
-      slot_i = slot_i + 1 == kBRing ? 0 : slot_i + 1;
-    };
-    for (int q = 0; q < 4 && q < Q; ++q) issue();
-    int gq = 0;
-#ifdef RTPE_CONV_STAMPS
-    unsigned long long w0, w1, w2, w3, wwait = 0, wbar = 0, wissue = 0;
-#endif
-    for (int q = 0; q < Q; ++q) {
-      SSTAMP(w0);
-      // groups issued so far: <= q + 3; allowed in flight: q + 2, q + 3
-      if (q + 3 < Q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kBDmaPerGroup) : "memory");
-      else if (q + 2 < Q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBDmaPerGroup) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      SSTAMP(w1);
-      RTPE_SBARRIER();                                   // B(q)
       SSTAMP(w2);
-      if (q + 4 < Q) issue();
+      if (j >= 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBGroup * 3) : "memory");         // groups <= j - 1 have landed
+        flag_set(flg + kFWl + cb, (uint32_t)j, lane);
+      }
       SSTAMP(w3);
 #ifdef RTPE_CONV_STAMPS
-      wwait += w1 - w0; wbar += w2 - w1; wissue += w3 - w2;
+      wpoll += w1 - w0; wissue += w2 - w1; wwait += w3 - w2;
 #endif
-      if (++gq == kBGroupsPerUnit) {
-        gq = 0;
-        RTPE_SBARRIER();                                 // E2 of the unit
-      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_set(flg + kFWl + cb, 0x7fffffffu, lane);        // everything has landed (the look-ahead of the last groups asks for more)
 #ifdef RTPE_CONV_STAMPS
-    if (a.dbg != nullptr && lane == 0) { atomicAdd(&a.dbg[8], wwait); atomicAdd(&a.dbg[9], wbar); atomicAdd(&a.dbg[10], wissue); atomicAdd(&a.dbg[11], (unsigned long long)Q); }
+    if (a.dbg != nullptr && lane == 0 && cb == 0) { atomicAdd(&a.dbg[8], wpoll); atomicAdd(&a.dbg[9], wwait); atomicAdd(&a.dbg[10], wissue); atomicAdd(&a.dbg[11], (unsigned long long)Q); }
 #endif
     return;
   }
 
-  if (wv > kBWaves) {
-    // ------------------------------ tile loaders ------------------------------
-    const int jl = wv - kBWaves - 1;                     // rows [0,7) or [7,14) of both chunk buffers
+  if (wv >= 6) {
+    // ------------------------- tile + store waves -------------------------
+    // wave jl: rows [7 jl, 7 jl + 7) of both x chunk buffers; and output rows [5 jl, 5 jl + 5) of the unit, whole pixels
+    // (both channel halves): residual pieces out of the x tile when conv1 is done with it, then the next tile's request,
+    // then - when the four MFMA waves have left BN2's rows in their slabs - add, ReLU and the 16-byte row stores, beside
+    // the next unit's first conv.  60 + 60 registers of row pieces, no MFMA wave waits for a store.
+    const int jl = wv - 6;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, a.x_bytes, 0x00020000);
     constexpr int rowslots = kBXW * 6;                   // 120 16-byte slots per halo row and chunk
     auto issue = [&](int u) __attribute__((always_inline)) {
@@ -208,39 +284,86 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
         }
       }
     };
+    // row piece `it` of this lane: pixel pw (of the wave's 80) x 16-byte slot s (12 per pixel: 6 per channel half)
+    int soff_[kBSNIT], xoff_[kBSNIT], epos_[kBSNIT];
+#pragma unroll
+    for (int it = 0; it < kBSNIT; ++it) {
+      const int c = it * 64 + lane;                      // < 960: every piece exists
+      const int pw = c / 12, s = c - pw * 12;
+      const int hcs = s >= 6, sl = s - 6 * hcs;
+      const int oy = jl * kBNT2 + (pw >> 4), ox = pw & 15;
+      soff_[it] = (hcs + 2 * jl) * (kBNT2 * 16 * kBRowB) + pw * kBRowB + sl * 16;              // slab of MFMA wave (hcs, jl)
+      xoff_[it] = hcs * kBXBytes + (oy + 2) * kBXPitch + (ox + 2) * kBPS + sl * 16;
+      epos_[it] = (oy << 16) | (ox << 8) | (hcs << 7) | (sl * 16);
+    }
     issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag_set(flg + kFXl + jl, 1u, lane);
 #ifdef RTPE_CONV_STAMPS
-    unsigned long long t0, t1, twait = 0;
+    unsigned long long t0, t1, t2, t3, t4, tpoll1 = 0, tdma = 0, tpoll2 = 0, tstore = 0, tread = 0;
 #endif
     for (int u = 0; u < U; ++u) {
+      uint32_t n;
+      int py0, px0;
+      unit_origin(u, &n, &py0, &px0);
       SSTAMP(t0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this loader's rows of tile u have landed
+      wait_min4<kSleepS>(flg + kFProg, (uint32_t)(kBGroupsPerUnit * u + kBGroupsPerConv), flg + kFWords - 1);   // conv1 of unit u is done with the x tile
+      half8 rv[kBSNIT];
+#pragma unroll
+      for (int it = 0; it < kBSNIT; ++it) rv[it] = *reinterpret_cast<const half8*>(xt + xoff_[it]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       SSTAMP(t1);
+      if (u + 1 < U) {
+        issue(u + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (also the previous unit's stores)
+        flag_set(flg + kFXl + jl, (uint32_t)(u + 2), lane);
+      }
+      SSTAMP(t2);
+      wait_min4<kSleepS>(flg + kFSlabR, (uint32_t)(u + 1), flg + kFWords - 1);  // BN2's rows of unit u are in the four slabs
+      SSTAMP(t3);
+      half8 ov[kBSNIT];
+#pragma unroll
+      for (int it = 0; it < kBSNIT; ++it) ov[it] = *reinterpret_cast<const half8*>(mid + soff_[it]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      flag_set(flg + kFSlabD + jl, (uint32_t)(u + 1), lane);   // the slab rows are in registers: the mid tile may be rewritten
 #ifdef RTPE_CONV_STAMPS
-      twait += t1 - t0;
+      unsigned long long t3b;
+      SSTAMP(t3b);
+      tread += t3b - t3;
 #endif
-      for (int b = 0; b < kBGroupsPerConv; ++b) RTPE_SBARRIER();          // B(0) .. B(13): conv1
-      RTPE_SBARRIER();                                   // B(14): conv1 is done with the x tile, the residual is in registers
-      if (u + 1 < U) issue(u + 1);
-      for (int b = kBGroupsPerConv + 1; b < kBGroupsPerUnit; ++b) RTPE_SBARRIER();   // B(15) .. B(27)
-      RTPE_SBARRIER();                                   // E2
+      const int hy = a.H - py0, hx = a.W - px0;
+      char* const yb = reinterpret_cast<char*>(a.y + (((size_t)n * a.H + py0) * a.W + px0) * a.out_ld);
+      const uint32_t ld2 = (uint32_t)a.out_ld * 2u, row_pix = (uint32_t)a.W & 0xffffffu;
+      const uint32_t cs2 = (uint32_t)(a.out_cs * 2);
+#pragma unroll
+      for (int it = 0; it < kBSNIT; ++it) {
+        int e = epos_[it];
+        asm volatile("" : "+v"(e));                      // lane-only math must not be hoisted out of the unit loop
+        half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
+        short8 b = __builtin_bit_cast(short8, v);
+        b = b & ~(b >> 15);
+        if ((e >> 16) < hy && ((e >> 8) & 255) < hx && !RTPE_B96_ABL(a, 4)) {
+          const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
+          store16_wt(yb + __umul24(pix, ld2) + (((uint32_t)e >> 7) & 1u) * cs2 + ((uint32_t)e & 127u), b);
+        }
+      }
+      SSTAMP(t4);
+#ifdef RTPE_CONV_STAMPS
+      tpoll1 += t1 - t0; tdma += t2 - t1; tpoll2 += t3 - t2; tstore += t4 - t3;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RTPE_CONV_STAMPS
-    if (a.dbg != nullptr && lane == 0) atomicAdd(&a.dbg[12], twait);
+    if (a.dbg != nullptr && lane == 0 && jl == 0) { atomicAdd(&a.dbg[12], tpoll1); atomicAdd(&a.dbg[13], tdma); atomicAdd(&a.dbg[14], tpoll2); atomicAdd(&a.dbg[15], tstore); atomicAdd(&a.dbg[28], tread);
+      unsigned long long t_end; SSTAMP(t_end); atomicAdd(&a.dbg[29], t_end - k_start); atomicMax(&a.dbg[31], t_end - k_start); }
 #endif
     return;
   }
 
   // -------------------------------- MFMA waves --------------------------------
   const int r = lane & 15, g = lane >> 4;
-  const int hc = wv & 1;                                 // cout half (and the mid plane / residual chunk of this wave)
+  const int hc = wv & 1;                                 // cout half (and the mid plane this wave writes)
   const int hq = wv >> 1;                                // pixel half
-  // BN parameters of both convs -> LDS (read back per epilogue: 48 registers would otherwise live through the k loops)
-  for (int i = tid; i < 2 * 2 * 96; i += kBWaves * 64) {
-    const int c = i / 192, j = i - c * 192;
-    bnp[i] = (c ? a.ab2 : a.ab1)[j];
-  }
   // byte offset of this lane group's 8 channels in k-step k of a chunk: conv1 walks an x chunk buffer, conv2 a mid plane
   int toff1[14], toff2[14];
 #pragma unroll
@@ -262,31 +385,24 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
   }
 #pragma unroll
   for (int nt = 0; nt < kBNT2; ++nt) pix2[nt] = (hq * kBNT2 + nt) * kBMPitch + r * kBPS;
-  // epilogue B, 16-byte row piece `it` of this lane: where it is in the wave's transposed slab (eoff), in the x chunk
-  // buffer of this wave's channel half (xoff: the residual), and its position in the output tile
-  int eoff[kBNIT], xoff[kBNIT], epos[kBNIT];
-#pragma unroll
-  for (int it = 0; it < kBNIT; ++it) {
-    int c = it * 64 + lane;
-    const bool exists = c < kBNT2 * 16 * 6;
-    c = exists ? c : 0;
-    const int pw = c / 6, slot = c - pw * 6;
-    const int oy = hq * kBNT2 + (pw >> 4), ox = pw & 15;
-    eoff[it] = pw * kBRowB + slot * 16;
-    xoff[it] = (oy + 2) * kBXPitch + (ox + 2) * kBPS + slot * 16;
-    epos[it] = ((exists ? oy : 0x7fff) << 16) | (ox << 8) | (slot * 16);
-  }
-  const char* const xres = xt + hc * kBXBytes;
   char* const midw = mid + hc * kBMidPlane;              // epilogue A writes this wave's 48 channels: plane hc
   char* const obuf = mid + wv * (kBNT2 * 16 * kBRowB);
   const char* const ringl = ring + lane * 16 + hc * 3 * 1024;
-  int slot = 0;                                          // ring slot of the next group (q % 5)
+  int slot = 0;                                          // ring slot of the next group (count % 5)
+  uint32_t gcount = 0;                                   // ring groups this wave is done with
+  uint32_t wl_seen = 0;                                  // groups known to have landed (both loaders)
+  uint2v wl_pre = uint2v{0u, 0u};                        // the landed counts, read one group ago
+#ifdef RTPE_CONV_STAMPS
+  unsigned long long wl_spins = 0;
+#endif
 
   // One chunk pass = 14 k-steps = 7 groups of the ring, fully unrolled.  A fragments: double-buffered, read one k-step
-  // ahead (the barrier of a group guarantees the NEXT group too, so the look-ahead may cross a group).  B fragments: ONE
-  // register set - a fragment is re-read for the next k-step right after the three MFMAs that use it.  FIRST: the pass
-  // starts cold (its operands are read behind its first barrier); NEXT: the last k-step reads the first operands of the
-  // pass that follows (bnext; same tap table).
+  // ahead (a group is started only when the NEXT group has landed too, so the look-ahead may cross a group).  B fragments:
+  // ONE register set - a fragment is re-read for the next k-step right after the three MFMAs that use it.  FIRST: the
+  // pass starts cold (its operands are read behind its first check); NEXT: the last k-step reads the first operands of
+  // the pass that follows (bnext; same tap table).  No workgroup barrier: the landed counts are read one group ahead of
+  // their use (the loaders run three groups ahead, so the check almost never waits), and a finished group is counted in
+  // this wave's progress word, which the loaders poll before they overwrite a slot.
   auto chunk_pass = [&](auto& acc, half8 (&af)[2][3], auto& bf, const char* bcur, const char* bnext, const auto& pix,
                         const int (&toff)[14], auto first_c, auto next_c) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_c)::value, NEXT = decltype(next_c)::value;
@@ -295,7 +411,18 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
     for (int k = 0; k < 14; ++k) {
       const int cur = k & 1, nxt = cur ^ 1;
       if ((k & 1) == 0) {
-        RTPE_SBARRIER();                                 // B(q): this group and the next one are in the ring
+        const uint32_t need = gcount + 2;                // this group and the next one
+        if (wl_seen < need) {
+          wl_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(wl_pre[0], wl_pre[1]));
+          for (int spins = 0; wl_seen < need && spins < kSpinCap; ++spins) {
+            wl_seen = flag_min2(flg + kFWl);
+#ifdef RTPE_CONV_STAMPS
+            ++wl_spins;
+#endif
+          }
+        }
+        asm volatile("" ::: "memory");
+        wl_pre = *(lds_flag2_t*)(flg + kFWl);
         if (FIRST && k == 0) {
           const char* wl = ringl + slot * kBSlot;
 #pragma unroll
@@ -341,13 +468,18 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (k & 1) slot = slot + 1 == kBRing ? 0 : slot + 1;
+      if (k & 1) {
+        // every read of this group's slot has been issued (LDS executes them before the count below)
+        slot = slot + 1 == kBRing ? 0 : slot + 1;
+        gcount += 1;
+        flag_set(flg + kFProg + wv, gcount, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
 #ifdef RTPE_CONV_STAMPS
   unsigned long long st[8] = {0}, m0, m1, m2, m3, m4, m5, m6, m7;
-  const unsigned long long k_begin = __builtin_readcyclecounter();
 #endif
   for (int u = 0; u < U; ++u) {
     uint32_t n;
@@ -355,6 +487,7 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
     unit_origin(u, &n, &py0, &px0);
     half8 af[2][3];
     SSTAMP(m0);
+    wait_min2<0>(flg + kFXl, (uint32_t)(u + 1), flg + kFWords - 1);     // the x tile of this unit has landed
 
     // ------------------------------- conv1 -------------------------------
     float4v acc1[3][kBNT1];
@@ -369,10 +502,6 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
       chunk_pass(acc1, af, bf, xt + kBXBytes, xt, pix1, toff1, std::false_type(), std::false_type());
     }
     SSTAMP(m2);
-    // the residual: this wave's row pieces of the block input, out of the x tile before it is released
-    half8 rv[kBNIT];
-#pragma unroll
-    for (int it = 0; it < kBNIT; ++it) rv[it] = *reinterpret_cast<const half8*>(xres + xoff[it]);
     // ---- epilogue A: BN1 + ReLU -> fp16 rows of the mid tile (the unfused path's HBM tensor) ----
     {
       int lane_e = lane;
@@ -384,6 +513,7 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
         al[m] = *reinterpret_cast<const float4v*>(bnp + (hc * 3 + m) * 16 + ge * 4);
         be[m] = *reinterpret_cast<const float4v*>(bnp + 96 + (hc * 3 + m) * 16 + ge * 4);
       }
+      wait_min2<0>(flg + kFSlabD, (uint32_t)u, flg + kFWords - 1);      // the previous unit's output rows have left the mid tile
       if (!RTPE_B96_ABL(a, 2)) {
 #pragma unroll
         for (int nt = 0; nt < kBNT1; ++nt) {
@@ -402,7 +532,8 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // mid rows written, residual pieces read: the x tile is free
+      flag_set(flg + kFMid + wv, (uint32_t)(u + 1), lane);
+      wait_min4<0>(flg + kFMid, (uint32_t)(u + 1), flg + kFWords - 1);   // all four waves' rows are in the mid tile
     }
 
     // ------------------------------- conv2 -------------------------------
@@ -419,7 +550,7 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
       chunk_pass(acc2, af, bf, mid + kBMidPlane, mid, pix2, toff2, std::false_type(), std::false_type());
     }
     SSTAMP(m5);
-    // ---- epilogue B: BN2, transposed through the (now free) mid tile, + x, ReLU, store ----
+    // ---- epilogue B: BN2 -> this wave's slab in the (then free) mid tile; the tile waves finish and store the rows ----
     {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
@@ -430,8 +561,7 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
         al[m] = *reinterpret_cast<const float4v*>(bnp + 192 + (hc * 3 + m) * 16 + ge * 4);
         be[m] = *reinterpret_cast<const float4v*>(bnp + 192 + 96 + (hc * 3 + m) * 16 + ge * 4);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      RTPE_SBARRIER();                                   // E2: every wave is done reading the mid tile
+      wait_min4<0>(flg + kFProg, (uint32_t)(kBGroupsPerUnit * (u + 1)), flg + kFWords - 1);   // every wave is done reading the mid tile
       SSTAMP(m6);
 #pragma unroll
       for (int nt = 0; nt < kBNT2; ++nt)
@@ -440,25 +570,7 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
           const half4 o_bn = bn_round(acc2[m][nt], al[m], be[m]);
           *reinterpret_cast<half4*>(obuf + (nt * 16 + re) * kBRowB + m * 32 + ge * 8) = o_bn;
         }
-      half8 ov[kBNIT];
-#pragma unroll
-      for (int it = 0; it < kBNIT; ++it) ov[it] = *reinterpret_cast<const half8*>(obuf + eoff[it]);
-      const int hy = a.H - py0, hx = a.W - px0;
-      char* const yb = reinterpret_cast<char*>(a.y + (((size_t)n * a.H + py0) * a.W + px0) * a.out_ld + (size_t)hc * a.out_cs);
-      const uint32_t ld2 = (uint32_t)a.out_ld * 2u, row_pix = (uint32_t)a.W & 0xffffffu;
-#pragma unroll
-      for (int it = 0; it < kBNIT; ++it) {
-        int e = epos[it];
-        asm volatile("" : "+v"(e));                      // lane-only math must not be hoisted out of the unit loop
-        half8 v = ov[it] + rv[it];                       // fp16 add, round-to-nearest-even = the wrapper's add
-        short8 b = __builtin_bit_cast(short8, v);
-        b = b & ~(b >> 15);
-        if ((e >> 16) < hy && ((e >> 8) & 255) < hx && !RTPE_B96_ABL(a, 4)) {
-          const uint32_t pix = __umul24((uint32_t)e >> 16, row_pix) + (((uint32_t)e >> 8) & 255u);
-          store16_wt(yb + __umul24(pix, ld2) + ((uint32_t)e & 255u), b);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is read: the next unit's epilogue A may overwrite it
+      flag_set(flg + kFSlabR + wv, (uint32_t)(u + 1), lane);
     }
 #ifdef RTPE_CONV_STAMPS
     SSTAMP(m7);
@@ -468,7 +580,10 @@ __global__ void __launch_bounds__((kBWaves + kBLoad) * 64) conv_block96_kernel(c
 #ifdef RTPE_CONV_STAMPS
   if (a.dbg != nullptr && lane == 0) {
     for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], st[i]);
-    atomicAdd(&a.dbg[13], __builtin_readcyclecounter() - k_begin);
+    atomicAdd(&a.dbg[16 + wv], st[1]);                   // per wave: conv1 pass 1, conv2 pass 1, polls of the landed counts
+    atomicAdd(&a.dbg[20 + wv], st[4]);
+    atomicAdd(&a.dbg[24 + wv], wl_spins);
+    if (wv == 0) { unsigned long long t_end; SSTAMP(t_end); atomicAdd(&a.dbg[30], t_end - k_start); }
   }
 #endif
 }
@@ -513,7 +628,7 @@ int conv_block96_launch(const _Float16* x, int in_ld, long long in_cs, size_t x_
   static const int g_env = env_int("RTPE_PERSIST_G", 32);
   long G = g_env;                                         // one workgroup per CU
   if (G > (tiles + 7) / 8) G = (tiles + 7) / 8;
-  hipLaunchKernelGGL(conv_block96_kernel, dim3((unsigned)(8 * G)), dim3((kBWaves + kBLoad) * 64), kBLds, s, a);
+  hipLaunchKernelGGL(conv_block96_kernel, dim3((unsigned)(8 * G)), dim3(512), kBLds, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
   return RTPE_OK;
 }

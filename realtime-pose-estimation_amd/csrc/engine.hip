@@ -1066,8 +1066,8 @@ extern "C" int rtpe_basicblock_nhwc_ex(const void* x, int32_t N, int32_t H, int3
   else {
     unsigned long long* dbg = nullptr;
 #ifdef RTPE_CONV_STAMPS
-    hipMalloc(reinterpret_cast<void**>(&dbg), 128);
-    hipMemset(dbg, 0, 128);
+    hipMalloc(reinterpret_cast<void**>(&dbg), 256);
+    hipMemset(dbg, 0, 256);
 #endif
     // stamps builds, RTPE_PROBE_PLANE=1 / 2: time the launch with plane-major views of the output / of both tensors over the
     // same bytes ([2][N][H][W][48], what the executor gives the inner tensors of the branch's block chain) - values meaningless
@@ -1080,17 +1080,19 @@ extern "C" int rtpe_basicblock_nhwc_ex(const void* x, int32_t N, int32_t H, int3
                              probe_plane >= 1 ? 48 : 96, probe_plane >= 1 ? pl : 48, w1, ab1, w2, ab2, N, H, W, s, dbg);
 #ifdef RTPE_CONV_STAMPS
     hipStreamSynchronize(s);
-    unsigned long long hd[16];
-    hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost);
+    unsigned long long hd[32];
+    hipMemcpy(hd, dbg, 256, hipMemcpyDeviceToHost);
     hipFree(dbg);
     if (hd[7]) {
-      const unsigned long long nu = hd[7], q = hd[11] ? hd[11] : 1;                  // (4 MFMA waves count each unit)
-      const long tiles96 = (long)N * ((H + 9) / 10) * ((W + 15) / 16);
-      const unsigned long long nwg = (unsigned long long)(8 * (tiles96 + 7 >= 8 * 32 ? 32 : (tiles96 + 7) / 8));
-      fprintf(stderr, "block96 %dx%d n%d | per MFMA wave and unit (cycles): conv1 pass0 %llu pass1 %llu | residual + epilogue A %llu | conv2 pass0 %llu "
-              "pass1 %llu | E2 wait %llu | epilogue B %llu | kernel per wave %llu (units per wave %.2f) | weight loader per group: vmcnt wait %llu barrier wait %llu "
-              "issue %llu | tile loader vmcnt wait per unit %llu\n", H, W, N, hd[0] / nu, hd[1] / nu, hd[2] / nu, hd[3] / nu, hd[4] / nu, hd[5] / nu, hd[6] / nu,
-              hd[13] / (4 * nwg), (double)nu / 4.0 / (double)nwg, hd[8] / q, hd[9] / q, hd[10] / q, hd[12] / (nu / 2 ? nu / 2 : 1));
+      fprintf(stderr, "block96 per MFMA wave 0..3 and unit: conv1 pass1 %llu %llu %llu %llu | conv2 pass1 %llu %llu %llu %llu | polls of the landed counts %llu %llu %llu %llu\n",
+              hd[16] * 4 / hd[7], hd[17] * 4 / hd[7], hd[18] * 4 / hd[7], hd[19] * 4 / hd[7], hd[20] * 4 / hd[7], hd[21] * 4 / hd[7], hd[22] * 4 / hd[7],
+              hd[23] * 4 / hd[7], hd[24] * 4 / hd[7], hd[25] * 4 / hd[7], hd[26] * 4 / hd[7], hd[27] * 4 / hd[7]);
+      fprintf(stderr, "block96 kernel span per workgroup (cycles): MFMA wave 0 %llu, store wave 0 mean %llu max %llu\n", hd[30] * 20 / hd[7], hd[29] * 20 / hd[7], hd[31]);
+      const unsigned long long nu = hd[7], q = hd[11] ? hd[11] : 1, nsu = nu / 4 ? nu / 4 : 1;   // (4 MFMA waves count each unit)
+      fprintf(stderr, "block96 %dx%d n%d | per MFMA wave and unit (cycles): x wait + conv1 pass0 %llu pass1 %llu | epilogue A (+ waits) %llu | conv2 pass0 %llu "
+              "pass1 %llu | mid-free wait %llu | BN2 -> slab %llu | weight loader 0 per group: slot wait %llu issue %llu landed wait %llu | store wave 0 per unit: "
+              "conv1 wait + residual %llu next tile %llu slab wait %llu rows + stores %llu (slab reads %llu)\n", H, W, N, hd[0] / nu, hd[1] / nu, hd[2] / nu, hd[3] / nu, hd[4] / nu,
+              hd[5] / nu, hd[6] / nu, hd[8] / q, hd[10] / q, hd[9] / q, hd[12] / nsu, hd[13] / nsu, hd[14] / nsu, hd[15] / nsu, hd[28] / nsu);
     }
 #endif
   }

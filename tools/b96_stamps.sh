@@ -3,7 +3,7 @@
 # put a select behind every MFMA); ABLS="0 1 16" adds a diagnostic build with those.    bash tools/b96_stamps.sh <out file>
 out=${1:-gpurun_out/b96_stamps.txt}
 root=$(cd "$(dirname "$0")/.." && pwd)
-tools/build_variant.sh stamps -DRTPE_CONV_STAMPS > /dev/null 2>&1 || exit 1
+tools/build_variant.sh stamps -DRTPE_CONV_STAMPS $STAMP_DEFS > /dev/null 2>&1 || exit 1
 export RTPE_LIBRARY=$root/realtime-pose-estimation_amd/librtpe_stamps.so
 : > $out
 timeout -k 10 300 python tools/conv_probe.py block96,80,80,32 96,96,3,1,80,80,32,1 >> $out 2>&1 || exit 1
