@@ -65,7 +65,7 @@ extern "C" {
 #define RTPE_DTYPE_F32 2
 
 const char* rtpe_last_error_string(void);
-/* ABI revision: 4 = rtpe_basicblock_nhwc_ex, option "block96"; option "stream_pc" and ConvTile kind 3 are gone (a tuned-shape
+/* ABI revision: 4 = option "stream_pc" and ConvTile kind 3 are gone (a tuned-shape
  * file that names kind 3 is refused by rtpe_hrnet_import_tuned); the Python binding
  * refuses a library of another revision (RTPE_LIBRARY);
  * 3 = tuned-shape records have 11 integers (RTPE_TUNED_INTS);
@@ -271,10 +271,7 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * the fused kernel's conv1 code (its multiply-add chain on the matrix pipe; a test setting).  Same bits in all three.
  * "conv64" (env RTPE_CONV64): the 3x3 stride-1 convs with 64 input and 64 output channels and no residual (conv2 of layer1's
  * Bottlenecks) run 1 = on persistent workgroups with double-buffered halo tiles and register-resident weights
- * (csrc/conv64.hip; default, and one more launch shape for the autotuner), 0 = on the one-workgroup-per-tile kernel.
- * "block96" (env RTPE_BLOCK96): the BasicBlocks of the 96-channel branch run 1 = as one fused kernel that keeps the
- * intermediate tensor in LDS and streams both weight sets through an LDS ring (csrc/conv_block96.hip; default), 0 = as two
- * launches of the streaming kernel.  Same bits. */
+ * (csrc/conv64.hip; default, and one more launch shape for the autotuner), 0 = on the one-workgroup-per-tile kernel. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */
@@ -327,13 +324,6 @@ int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, int32_t H, in
 int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t W, const void* w1_host,
                          const float* alpha1, const float* beta1, const void* w2_host,
                          const float* alpha2, const float* beta2, void* y, void* stream);
-/* The same for a branch of `channels` = 48 or 96 channels (96: csrc/conv_block96.hip, the BasicBlocks of the second
- * branch; NHWC fp16 (N,H,W,channels) in and out, weights (channels,channels,3,3), alpha/beta[channels]).  RTPE_E_INVALID
- * for other channel counts and for maps the fused kernel does not take (the executor runs those as two launches). */
-int rtpe_basicblock_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t W, int32_t channels, const void* w1_host,
-                            const float* alpha1, const float* beta1, const void* w2_host,
-                            const float* alpha2, const float* beta2, void* y, void* stream);
-
 /* ConvTranspose2d(k=4, s=2, p=1, no bias) + BatchNorm (+ReLU), pose_higher_hrnet.py:513-524, as the
  * four sub-pixel 2x2 convolutions the executor runs.  x NHWC fp16 (N,H,W,cin); w_host the PyTorch
  * (cin, cout, 4, 4) fp16 weight; y NHWC fp16 (N,2H,2W,cout).  Host-returning (layer-level tests). */

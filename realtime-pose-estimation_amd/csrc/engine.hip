@@ -78,10 +78,10 @@ struct rtpe_hrnet {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "block96"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_BLOCK96"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -210,8 +210,7 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
     const rtpe_op_desc& d2 = a2.d;
     const int plain = RTPE_F_RELU | RTPE_F_ROUND_CONV;
     if (a1.fuse || d1.kind != RTPE_OP_CONV || d2.kind != RTPE_OP_CONV) continue;
-    // (48 channels: conv_block.hip; 96 channels: conv_block96.hip)
-    if ((d1.cin != 48 && d1.cin != 96) || d1.cout != d1.cin || d2.cin != d1.cin || d2.cout != d1.cin || d1.ksize != 3 || d2.ksize != 3 ||
+    if (d1.cin != 48 || d1.cout != 48 || d2.cin != 48 || d2.cout != 48 || d1.ksize != 3 || d2.ksize != 3 ||
         d1.stride != 1 || d2.stride != 1 || d1.flags != plain || d2.flags != plain || d1.res_t >= 0 ||
         d2.res_t != d1.in_t || d2.res_coff != d1.in_coff || d2.in_t != d1.out_t || d2.in_coff != d1.out_coff ||
         d1.reserved[1] > 1 || d2.reserved[1] > 1 || h->tensors[d1.in_t].reserved == 4 || d2.out_t == d1.in_t)
@@ -407,14 +406,13 @@ extern "C" int rtpe_hrnet_workspace_bytes(const rtpe_hrnet* h, int32_t N, int32_
   return RTPE_OK;
 }
 
-// a fused BasicBlock pair (OpState::fuse) runs as one kernel at this map size: the 48-channel kernels from 6 x 16 maps up,
-// the 96-channel kernel (option "block96") where its 10 x 16 tiles do not waste too much of the map
+// a fused BasicBlock pair (OpState::fuse) runs as one kernel at this map size (conv_block.hip: 48 channels, from 6 x 16 maps up).
+// (A fused kernel for the 96-channel branch was built and measured in round 5 - slower than the two streaming launches:
+// profiles/r05_block96_ablation.txt, tools/experiments/conv_block96.hip.)
 static bool fused_block_runs(const rtpe_hrnet* h, const rtpe_op_desc& d, int N, int H, int W) {
   const rtpe_tensor_desc& ti = h->tensors[d.in_t];
-  const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
-  if (d.cin == 48) return conv_block_supports(d.cin, d.cout, Hi, Wi);
-  return d.cin == 96 && get_option(kOptBlock96) != 0 && conv_block96_pays(Hi, Wi) &&
-         (size_t)N * Hi * Wi * ti.channels * 2 < 0x80000000ull;
+  (void)N;
+  return conv_block_supports(d.cin, d.cout, H >> ti.ds_log2, W >> ti.ds_log2);
 }
 
 // plane-major tensors of one run: the candidates all of whose ops run on the streaming kernel with the launch
@@ -426,7 +424,6 @@ static std::vector<char> plane_tensors(const rtpe_hrnet* h, int N, int H, int W,
     const rtpe_op_desc& d = o.d;
     if (d.kind != RTPE_OP_CONV || o.n_geom != 1) continue;
     if (!(plane[d.in_t] || plane[d.out_t] || (d.res_t >= 0 && plane[d.res_t]))) continue;
-    if (o.fuse && d.cin == 96 && fused_block_runs(h, d, N, H, W)) continue;    // conv_block96.hip reads and writes either layout
     const rtpe_tensor_desc& ti = h->tensors[d.in_t];
     const ConvTile t = (tuned && (*tuned)[i * 4].nt) ? (*tuned)[i * 4]
                                                       : conv_make_tile(o.plan[0], N, H >> ti.ds_log2, W >> ti.ds_log2);
@@ -652,17 +649,7 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
       const OpState& o2 = h->ops[i + 1];
       const rtpe_tensor_desc& to = h->tensors[o2.d.out_t];
-      if (d.cin == 96) {
-        // x / y NHWC or plane-major (the inner tensors of the branch's block chain); the mid tensor is never written
-        const long long pl = (long long)N * Hi * Wi * 48;
-        RTPE_HP_LAUNCH(rc = conv_block96_launch(tptr(d.in_t, d.in_coff), plane[d.in_t] ? 48 : ti.channels, plane[d.in_t] ? pl : 48,
-                               ((size_t)N * Hi * Wi * ti.channels - (size_t)d.in_coff) * 2,
-                               tptr(o2.d.out_t, o2.d.out_coff), plane[o2.d.out_t] ? 48 : to.channels, plane[o2.d.out_t] ? pl : 48,
-                               reinterpret_cast<const _Float16*>(h->arena + o.w_dev_off[0]),
-                               reinterpret_cast<const float*>(h->arena + o.ab_dev_off),
-                               reinterpret_cast<const _Float16*>(h->arena + o2.w_dev_off[0]),
-                               reinterpret_cast<const float*>(h->arena + o2.ab_dev_off), N, Hi, Wi, s));
-      } else {
+      {
         RTPE_HP_LAUNCH(rc = conv_block_launch(tptr(d.in_t, d.in_coff), ti.channels,
                                ((size_t)N * Hi * Wi * ti.channels - (size_t)d.in_coff) * 2,
                                tptr(o2.d.out_t, o2.d.out_coff), to.channels,
@@ -1032,17 +1019,15 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   return RTPE_OK;
 }
 
-extern "C" int rtpe_basicblock_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t W, int32_t channels, const void* w1_host,
-                                       const float* alpha1, const float* beta1, const void* w2_host, const float* alpha2,
-                                       const float* beta2, void* y, void* stream) {
+extern "C" int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t W, const void* w1_host,
+                                    const float* alpha1, const float* beta1, const void* w2_host, const float* alpha2,
+                                    const float* beta2, void* y, void* stream) {
   RTPE_REQUIRE(x && w1_host && w2_host && alpha1 && beta1 && alpha2 && beta2 && y, "basicblock_nhwc: null argument");
-  const int C = channels;
-  RTPE_REQUIRE(C == 48 || C == 96, "basicblock_nhwc: %d channels (the fused kernels exist for 48 and 96)", C);
-  RTPE_REQUIRE(C == 48 ? conv_block_supports(48, 48, H, W) : conv_block96_supports(H, W), "basicblock_nhwc: H=%d W=%d unsupported", H, W);
+  RTPE_REQUIRE(conv_block_supports(48, 48, H, W), "basicblock_nhwc: H=%d W=%d unsupported", H, W);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  ConvGeom g{C, C, 3, 1, -1, 2, 1};
+  ConvGeom g{48, 48, 3, 1, -1, 2, 1};
   ConvPlan p = conv_make_plan(g);
-  const size_t wb = align_up(p.packed_bytes, 256), abb = align_up(2 * C * sizeof(float), 256);
+  const size_t wb = align_up(p.packed_bytes, 256), abb = align_up(2 * 48 * sizeof(float), 256);
   std::vector<char> host(2 * (wb + abb), 0);
   const void* ws[2] = {w1_host, w2_host};
   const float* al[2] = {alpha1, alpha2};
@@ -1050,63 +1035,21 @@ extern "C" int rtpe_basicblock_nhwc_ex(const void* x, int32_t N, int32_t H, int3
   for (int k = 0; k < 2; ++k) {
     conv_pack_weights(g, p, ws[k], host.data() + k * (wb + abb));
     float* ab = reinterpret_cast<float*>(host.data() + k * (wb + abb) + wb);
-    for (int c = 0; c < C; ++c) { ab[c] = al[k][c]; ab[C + c] = be[k][c]; }
+    for (int c = 0; c < 48; ++c) { ab[c] = al[k][c]; ab[48 + c] = be[k][c]; }
   }
   char* dev = nullptr;
   RTPE_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), host.size()));
   hipError_t e = hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) { hipFree(dev); return hip_fail(e, "hipMemcpy", __FILE__, __LINE__); }
-  const _Float16* xd = reinterpret_cast<const _Float16*>(x);
-  _Float16* yd = reinterpret_cast<_Float16*>(y);
-  const _Float16 *w1 = reinterpret_cast<const _Float16*>(dev), *w2 = reinterpret_cast<const _Float16*>(dev + wb + abb);
-  const float *ab1 = reinterpret_cast<const float*>(dev + wb), *ab2 = reinterpret_cast<const float*>(dev + wb + abb + wb);
-  int rc;
-  if (C == 48)
-    rc = conv_block_launch(xd, 48, (size_t)N * H * W * 48 * 2, yd, 48, w1, ab1, w2, ab2, N, H, W, s);
-  else {
-    unsigned long long* dbg = nullptr;
-#ifdef RTPE_CONV_STAMPS
-    hipMalloc(reinterpret_cast<void**>(&dbg), 256);
-    hipMemset(dbg, 0, 256);
-#endif
-    // stamps builds, RTPE_PROBE_PLANE=1 / 2: time the launch with plane-major views of the output / of both tensors over the
-    // same bytes ([2][N][H][W][48], what the executor gives the inner tensors of the branch's block chain) - values meaningless
-    int probe_plane = 0;
-#ifdef RTPE_CONV_STAMPS
-    probe_plane = env_int("RTPE_PROBE_PLANE", 0);
-#endif
-    const long long pl = (long long)N * H * W * 48;
-    rc = conv_block96_launch(xd, probe_plane >= 2 ? 48 : 96, probe_plane >= 2 ? pl : 48, (size_t)N * H * W * 96 * 2, yd,
-                             probe_plane >= 1 ? 48 : 96, probe_plane >= 1 ? pl : 48, w1, ab1, w2, ab2, N, H, W, s, dbg);
-#ifdef RTPE_CONV_STAMPS
-    hipStreamSynchronize(s);
-    unsigned long long hd[32];
-    hipMemcpy(hd, dbg, 256, hipMemcpyDeviceToHost);
-    hipFree(dbg);
-    if (hd[7]) {
-      fprintf(stderr, "block96 per MFMA wave 0..3 and unit: conv1 pass1 %llu %llu %llu %llu | conv2 pass1 %llu %llu %llu %llu | polls of the landed counts %llu %llu %llu %llu\n",
-              hd[16] * 4 / hd[7], hd[17] * 4 / hd[7], hd[18] * 4 / hd[7], hd[19] * 4 / hd[7], hd[20] * 4 / hd[7], hd[21] * 4 / hd[7], hd[22] * 4 / hd[7],
-              hd[23] * 4 / hd[7], hd[24] * 4 / hd[7], hd[25] * 4 / hd[7], hd[26] * 4 / hd[7], hd[27] * 4 / hd[7]);
-      fprintf(stderr, "block96 kernel span per workgroup (cycles): MFMA wave 0 %llu, store wave 0 mean %llu max %llu\n", hd[30] * 20 / hd[7], hd[29] * 20 / hd[7], hd[31]);
-      const unsigned long long nu = hd[7], q = hd[11] ? hd[11] : 1, nsu = nu / 4 ? nu / 4 : 1;   // (4 MFMA waves count each unit)
-      fprintf(stderr, "block96 %dx%d n%d | per MFMA wave and unit (cycles): x wait + conv1 pass0 %llu pass1 %llu | epilogue A (+ waits) %llu | conv2 pass0 %llu "
-              "pass1 %llu | mid-free wait %llu | BN2 -> slab %llu | weight loader 0 per group: slot wait %llu issue %llu landed wait %llu | store wave 0 per unit: "
-              "conv1 wait + residual %llu next tile %llu slab wait %llu rows + stores %llu (slab reads %llu)\n", H, W, N, hd[0] / nu, hd[1] / nu, hd[2] / nu, hd[3] / nu, hd[4] / nu,
-              hd[5] / nu, hd[6] / nu, hd[8] / q, hd[10] / q, hd[9] / q, hd[12] / nsu, hd[13] / nsu, hd[14] / nsu, hd[15] / nsu, hd[28] / nsu);
-    }
-#endif
-  }
+  int rc = conv_block_launch(reinterpret_cast<const _Float16*>(x), 48, (size_t)N * H * W * 48 * 2,
+                             reinterpret_cast<_Float16*>(y), 48, reinterpret_cast<const _Float16*>(dev),
+                             reinterpret_cast<const float*>(dev + wb), reinterpret_cast<const _Float16*>(dev + wb + abb),
+                             reinterpret_cast<const float*>(dev + wb + abb + wb), N, H, W, s);
   hipError_t es = hipStreamSynchronize(s);
   hipFree(dev);
   if (rc != RTPE_OK) return rc;
   if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
   return RTPE_OK;
-}
-
-extern "C" int rtpe_basicblock_nhwc(const void* x, int32_t N, int32_t H, int32_t W, const void* w1_host,
-                                    const float* alpha1, const float* beta1, const void* w2_host, const float* alpha2,
-                                    const float* beta2, void* y, void* stream) {
-  return rtpe_basicblock_nhwc_ex(x, N, H, W, 48, w1_host, alpha1, beta1, w2_host, alpha2, beta2, y, stream);
 }
 
 extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_t W, int32_t cin,
@@ -1232,12 +1175,7 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     out8[7] = o.pair == 1 ? -800001 : -800002;
     return RTPE_OK;
   }
-  if (o.fuse && d.cin == 96 && fused_block_runs(h, d, N, H, W)) {   // fused 96-channel BasicBlock (conv_block96.hip): 10x16 tiles
-    out8[0] = 3; out8[1] = o.fuse == 1 ? 7 : 5; out8[2] = 4; out8[3] = 10; out8[4] = 16; out8[5] = 48; out8[6] = 2;
-    out8[7] = o.fuse == 1 ? -900001 : -900002;
-    return RTPE_OK;
-  }
-  if (o.fuse && d.cin == 48) {       // fused BasicBlock (conv_block.hip): 6x32 tiles, 5 + 3 pixel tiles per wave
+  if (o.fuse) {       // fused BasicBlock (conv_block.hip): 6x32 tiles, 5 + 3 pixel tiles per wave
     out8[0] = 3; out8[1] = o.fuse == 1 ? 5 : 3; out8[2] = 4; out8[3] = 6; out8[4] = 32; out8[5] = 48; out8[6] = 1;
     out8[7] = o.fuse == 1 ? -900001 : -900002;
     return RTPE_OK;

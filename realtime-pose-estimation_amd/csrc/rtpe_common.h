@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kOptBlock96 = 8, kNumOptions = 9 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kNumOptions = 8 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -236,14 +236,6 @@ int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_block_supports(int cin, int cout, int H, int W);
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,
                       const float* ab1, const _Float16* w2, const float* ab2, int N, int H, int W, hipStream_t s);
-
-// fused BasicBlock of the 96-channel branch (conv_block96.hip): same function, x and y NHWC (ld >= 96, chunk stride 48)
-// or plane-major ([2][N][H][W][48]: ld 48, chunk stride N*H*W*48 elements)
-bool conv_block96_supports(int H, int W);
-bool conv_block96_pays(int H, int W);      // the executor fuses a block only where this holds
-int conv_block96_launch(const _Float16* x, int in_ld, long long in_cs, size_t x_bytes, _Float16* y, int out_ld, long long out_cs,
-                        const _Float16* w1, const float* ab1, const _Float16* w2, const float* ab2, int N, int H, int W,
-                        hipStream_t s, unsigned long long* dbg = nullptr);   // dbg: -DRTPE_CONV_STAMPS builds, 16 cycle sums
 
 // ---- elementwise / stem (elementwise.hip) ---------------------------------
 struct FuseArgs {

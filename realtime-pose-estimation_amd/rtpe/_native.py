@@ -83,8 +83,6 @@ _SIGS = {
                                  c_int32, c_void_p, c_void_p]),
     "rtpe_basicblock_nhwc": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(c_float), POINTER(c_float),
                                        c_void_p, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p]),
-    "rtpe_basicblock_nhwc_ex": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(c_float), POINTER(c_float),
-                                       c_void_p, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p]),
     "rtpe_warp_normalize": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),
                                       POINTER(c_float), c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "rtpe_resize_combine": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32,

@@ -1631,77 +1631,6 @@ def test_fused_basicblock_equals_two_convs(nat, case):
         assert torch.equal(a, b), "variant %d: %d of %d elements differ" % (variant, (a != b).sum().item(), a.numel())
 
 
-BLOCK96_CASES = [
-    # N, H, W: the bench's map (80 x 80 at batch 32: five complete 10 x 16 tiles per workgroup), partial tiles on both axes,
-    # one tile, fewer tiles than workgroups, maps narrower / lower than a tile, several units per workgroup with partial tiles
-    (32, 80, 80), (2, 32, 48), (1, 23, 37), (3, 10, 16), (5, 70, 100), (3, 8, 24), (2, 16, 64), (9, 40, 56), (1, 5, 8),
-]
-
-
-@pytest.mark.parametrize("case", BLOCK96_CASES, ids=lambda c: "block96_n%d_%dx%d" % c)
-def test_fused_basicblock_96_equals_two_convs(nat, case):
-    """csrc/conv_block96.hip: a BasicBlock of the 96-channel branch (reference pose_higher_hrnet.py:46-75) as ONE kernel - the
-    intermediate tensor stays in LDS, both weight sets stream through an LDS ring - must be BIT-identical to the two launches
-    of the streaming kernel it replaces (same k order over the two 48-channel chunks, same rounding points), including image
-    borders (zero padding of BOTH convs), partial tiles, and 1 ... 5 units per workgroup"""
-    N, H, W = case
-    C = 96
-    g = torch.Generator().manual_seed(H * 1000 + W + 96)
-    x = torch.randn(N, H, W, C, generator=g).half()
-    ws = [((torch.rand(C, C, 3, 3, generator=g) * 2 - 1) / (C * 9) ** 0.5).half().contiguous().numpy() for _ in range(2)]
-    al = [(torch.rand(C, generator=g) * 0.4 + 0.8).numpy() for _ in range(2)]
-    be = [(torch.randn(C, generator=g) * 0.1).numpy() for _ in range(2)]
-    dev = torch.device("cuda:0")
-    xd = x.to(dev)
-    st = nat.stream_ptr(dev)
-    fpt = ctypes.POINTER(ctypes.c_float)
-    mid = torch.empty_like(xd)
-    ref = torch.empty_like(xd)
-    L = nat.lib()
-    nat.check(L.rtpe_conv2d_nhwc(xd.data_ptr(), N, H, W, C, ws[0].ctypes.data, al[0].ctypes.data_as(fpt),
-                                 be[0].ctypes.data_as(fpt), C, 3, 1, nat.F_RELU | nat.F_ROUND_CONV, None,
-                                 mid.data_ptr(), st))
-    nat.check(L.rtpe_conv2d_nhwc(mid.data_ptr(), N, H, W, C, ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
-                                 be[1].ctypes.data_as(fpt), C, 3, 1, nat.F_RELU | nat.F_ROUND_CONV, xd.data_ptr(),
-                                 ref.data_ptr(), st))
-    got = torch.full_like(xd, float("nan"))
-    nat.check(L.rtpe_basicblock_nhwc_ex(xd.data_ptr(), N, H, W, C, ws[0].ctypes.data, al[0].ctypes.data_as(fpt),
-                                        be[0].ctypes.data_as(fpt), ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
-                                        be[1].ctypes.data_as(fpt), got.data_ptr(), st))
-    torch.cuda.synchronize()
-    assert not torch.isnan(got.float()).any()
-    a, b = got.cpu().view(torch.int16), ref.cpu().view(torch.int16)
-    assert torch.equal(a, b), "%d of %d elements differ" % ((a != b).sum().item(), a.numel())
-    # and a second run over the same buffers gives the same bits (no state left behind in the ring / flags)
-    got2 = torch.full_like(xd, float("nan"))
-    nat.check(L.rtpe_basicblock_nhwc_ex(xd.data_ptr(), N, H, W, C, ws[0].ctypes.data, al[0].ctypes.data_as(fpt),
-                                        be[0].ctypes.data_as(fpt), ws[1].ctypes.data, al[1].ctypes.data_as(fpt),
-                                        be[1].ctypes.data_as(fpt), got2.data_ptr(), st))
-    torch.cuda.synchronize()
-    assert torch.equal(got2.cpu().view(torch.int16), b)
-
-
-def test_fused_96_channel_block_does_not_change_the_network_output(nat, teacher):
-    """option "block96": the BasicBlocks of the 96-channel branch as one kernel each (default) or as two launches of the
-    streaming kernel: the whole network must give the SAME bits, at a size where the branch's tensors are plane-major
-    between the blocks (640 x 640: 80 x 80 maps), at a non-square one with partial tiles (256 x 384: 32 x 48) and at one
-    where the fused kernel does not run at all (64 x 64: an 8 x 8 map)"""
-    model, sd = teacher("W2")
-    L = nat.lib()
-    for n, hw in ((2, (640, 640)), (3, (256, 384)), (2, (64, 64))):
-        x = synth.make_images(n, hw[0], hw[1], seed=29).to("cuda:0")
-        outs = []
-        for on in (1, 0):
-            nat.check(L.rtpe_set_option(b"block96", on))
-            try:
-                with torch.no_grad():
-                    preds, refined = model(x)
-                outs.append((preds.cpu().numpy(), refined.cpu().numpy()))
-            finally:
-                nat.check(L.rtpe_set_option(b"block96", 1))
-        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), hw
-
-
 # --------------------------------------------------------------------------- #
 # layer-level entries for the remaining op kinds: transposed conv, fuse sum
 # --------------------------------------------------------------------------- #

@@ -22,10 +22,10 @@ DEFAULT = ["48,48,3,1,160,160,32,1", "96,96,3,1,80,80,32,1", "192,192,3,1,40,40,
 
 
 def run_block(case, reps=3):
-    """case = block,H,W,N : the fused BasicBlock kernel (rtpe_basicblock_nhwc); block96,H,W,N : the 96-channel one"""
+    """case = block,H,W,N : the fused BasicBlock kernel (rtpe_basicblock_nhwc)"""
     kind, H, W, N = case.split(",")
     H, W, N = int(H), int(W), int(N)
-    C = 96 if kind == "block96" else 48
+    C = 48
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     x = torch.randn(N, H, W, C, generator=g).half().to(dev)
@@ -38,9 +38,9 @@ def run_block(case, reps=3):
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nat.check(nat.lib().rtpe_basicblock_nhwc_ex(x.data_ptr(), N, H, W, C, ws[0].ctypes.data, a.ctypes.data_as(fp),
-                                                    b.ctypes.data_as(fp), ws[1].ctypes.data, a.ctypes.data_as(fp),
-                                                    b.ctypes.data_as(fp), y.data_ptr(), nat.stream_ptr(dev)))
+        nat.check(nat.lib().rtpe_basicblock_nhwc(x.data_ptr(), N, H, W, ws[0].ctypes.data, a.ctypes.data_as(fp),
+                                                 b.ctypes.data_as(fp), ws[1].ctypes.data, a.ctypes.data_as(fp),
+                                                 b.ctypes.data_as(fp), y.data_ptr(), nat.stream_ptr(dev)))
         ts.append(time.perf_counter() - t0)
     print("%-28s host-inclusive best %.1f us" % (case, min(ts) * 1e6), flush=True)
 

@@ -412,6 +412,7 @@ __global__ void __launch_bounds__(512) conv_block96_kernel(const Block96Args a) 
       const int cur = k & 1, nxt = cur ^ 1;
       if ((k & 1) == 0) {
         const uint32_t need = gcount + 2;                // this group and the next one
+#ifndef RTPE_B96_NOSYNC                                  // (timing experiment: no checks, one progress count per pass - wrong results)
         if (wl_seen < need) {
           wl_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(wl_pre[0], wl_pre[1]));
           for (int spins = 0; wl_seen < need && spins < kSpinCap; ++spins) {
@@ -423,6 +424,7 @@ __global__ void __launch_bounds__(512) conv_block96_kernel(const Block96Args a) 
         }
         asm volatile("" ::: "memory");
         wl_pre = *(lds_flag2_t*)(flg + kFWl);
+#endif
         if (FIRST && k == 0) {
           const char* wl = ringl + slot * kBSlot;
 #pragma unroll
@@ -472,6 +474,9 @@ __global__ void __launch_bounds__(512) conv_block96_kernel(const Block96Args a) 
         // every read of this group's slot has been issued (LDS executes them before the count below)
         slot = slot + 1 == kBRing ? 0 : slot + 1;
         gcount += 1;
+#ifdef RTPE_B96_NOSYNC
+        if (k == 13)
+#endif
         flag_set(flg + kFProg + wv, gcount, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
