@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         v[j] = x;
         o[j] = (T)x;
       }
+      acc[m][nt] = v;                                  // (the NCHW pass below re-reads the finished values)
       T* orow = reinterpret_cast<T*>(obuf + (nt * 16 + r) * ROWB) + m * 16 + g * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) orow[j] = o[j];
@@ -413,30 +414,6 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
           }
         }
       }
-    }
-  }
-  if (nchw_rows) {
-    // heads, fp32 NCHW (tofp32 folded in): four consecutive pixels of a channel plane per lane, read back from the wave's
-    // slice of the transpose buffer - 16-byte stores, a tile row of a plane is one contiguous piece (straight from the
-    // registers a store instruction wrote four 64-byte segments: 176 us for the 17-channel head at 320 x 320, 3 TB/s)
-    constexpr int QUADS = NT * 4;
-    int n_ch = a.nchw_channels - co_base;
-    n_ch = n_ch > MT * 16 ? MT * 16 : n_ch;
-    for (int idx = lane; idx < QUADS * n_ch; idx += 64) {
-      const int c = idx / QUADS, q = idx - c * QUADS;
-      const uint32_t p = wv * NT * 16 + q * 4;
-      const uint32_t oyt = fdiv(p, a.div_tw);
-      const uint32_t oxt = p - oyt * a.tw;
-      const int py = py0 + (int)oyt, px = px0 + (int)oxt;
-      if (py >= a.H_pos || px >= a.W_pos) continue;
-      float4v out;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float x = (float)*reinterpret_cast<const T*>(obuf + (q * 4 + i) * ROWB + c * ES);
-        out[i] = a.relu ? (x > 0.f ? x : 0.f) : x;
-      }
-      const size_t oi = (((size_t)n * a.nchw_channels + co_base + c) * a.H_full + (py + oy_add)) * a.W_full + px + ox_add;
-      *reinterpret_cast<float4v*>(reinterpret_cast<float*>(a.y_nchw) + oi) = out;
     }
   }
   if (a.y != nullptr) {
@@ -477,6 +454,52 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       // must meet in L2: plain stores there - write-through made the deconv 222 -> 259 us)
       if (a.o_mul == 1) store16_wt(yout + pix * a.out_ld + ch, raw);
       else *reinterpret_cast<uint4*>(yout + pix * a.out_ld + ch) = raw;
+    }
+  }
+  if (nchw_rows) {
+    // heads, fp32 NCHW (tofp32 folded in): four consecutive pixels of a channel plane per lane, 16-byte stores - a tile row
+    // of a plane is one contiguous piece (straight from the registers a store instruction wrote four 64-byte segments:
+    // 176 us for the 17-channel head at 320 x 320).  Round 5: the values come from a CHANNEL-major copy of the wave's
+    // slab ([channel][pixel], pitch NT * 16 elements + 8 bytes: the four channel groups of a write land in four different
+    // bank octets), so a lane's four pixels are ONE 8-byte (fp16) / 16-byte (fp32) read; reading them as four elements
+    // of the pixel-major slab hit two banks with all 64 lanes (counter: 82 % of the LDS cycles were bank conflicts).
+    // The slab is the wave's own: its pixel-major rows (read above by the NHWC stores, in program order) are overwritten.
+    constexpr int CPITCH = NT * 16 * ES + 8;
+    constexpr bool kPlanes = MT * 16 * CPITCH <= NT * 16 * ROWB;      // (not for the 16-pixel waves of the smallest tiles)
+    if constexpr (kPlanes) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<T*>(obuf + (m * 16 + g * 4 + j) * CPITCH + (nt * 16 + r) * ES) = (T)acc[m][nt][j];
+    }
+    constexpr int QUADS = NT * 4;
+    int n_ch = a.nchw_channels - co_base;
+    n_ch = n_ch > MT * 16 ? MT * 16 : n_ch;
+    for (int idx = lane; idx < QUADS * n_ch; idx += 64) {
+      const int c = idx / QUADS, q = idx - c * QUADS;
+      const uint32_t p = wv * NT * 16 + q * 4;
+      const uint32_t oyt = fdiv(p, a.div_tw);
+      const uint32_t oxt = p - oyt * a.tw;
+      const int py = py0 + (int)oyt, px = px0 + (int)oxt;
+      if (py >= a.H_pos || px >= a.W_pos) continue;
+      T in4[4];
+      if constexpr (kPlanes) {
+        __builtin_memcpy(in4, obuf + c * CPITCH + q * 4 * ES, 4 * ES);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) in4[i] = *reinterpret_cast<const T*>(obuf + (q * 4 + i) * ROWB + c * ES);
+      }
+      float4v out;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x = (float)in4[i];
+        out[i] = a.relu ? (x > 0.f ? x : 0.f) : x;
+      }
+      const size_t oi = (((size_t)n * a.nchw_channels + co_base + c) * a.H_full + (py + oy_add)) * a.W_full + px + ox_add;
+      *reinterpret_cast<float4v*>(reinterpret_cast<float*>(a.y_nchw) + oi) = out;
     }
   }
 #ifdef RTPE_CONV_STAMPS
