@@ -466,10 +466,11 @@ def main():
 
     run_steps(args.warmup, False)
     fence()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     rec = run_steps(args.steps, True)
     fence()
     dt = time.perf_counter() - t0
+    host_cpu_ms = (time.process_time() - c0) / args.steps * 1e3      # CPU time of this rank's process (all threads) per step
     for k in range(min(args.steps, n_slots)):
         op_ms[:] += np.asarray(eng.read_record(k))
     n_rec = min(args.steps, n_slots)
@@ -656,7 +657,8 @@ def main():
                    "pipeline": "software-pipelined steps (TeacherPipeline.stream): %s forward(s) in flight on internal streams, "
                                "decode of batch k-1 beside forward k; the %d recorded steps run alone" % (
                                    os.environ.get("RTPE_FORWARDS_IN_FLIGHT", "2"), n_slots),
-                   "forward_only_images_per_sec_per_gpu": round(B / fwd_s, 1)},
+                   "forward_only_images_per_sec_per_gpu": round(B / fwd_s, 1),
+                   "host_cpu_ms_per_step": round(host_cpu_ms, 2), "host_threads": host_threads},
         # roofline = the time-dominant kernel family (MFMA-bound 3x3 convs with C >= 96); roofline_secondary = the fused
         # C = 48 BasicBlock (HBM-bound by SURVEY 8d's layer-fused bytes), the second-largest share of the forward
         "roofline": td if td is not None else roofline, "roofline_secondary": roofline if td is not None else None,

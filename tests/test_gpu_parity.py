@@ -325,6 +325,68 @@ def test_fused_stem_layer_level(nat, hw, n, f32in):
         assert err.max() <= 2.0 and same > 0.97
 
 
+def test_stem_chain_on_the_matrix_pipe_with_cancellation_and_fp16_denormals(nat):
+    """conv1 of the fused stem runs its 27-step fp32 multiply-add chain on the matrix pipe (seven v_mfma_f32_16x16x4_f32,
+    csrc/stem_fused.hip); its bit-identity to the VALU kernel's chain of fmaf steps was only exercised on ordinary random
+    data.  Here: (a) inputs and weights in the fp16 DENORMAL range (the smallest magnitudes the half wrapper can feed the
+    chain: products down to 3.6e-15 - fp32-denormal partial sums cannot occur, fp16 x fp16 products are >= 2^-48), (b)
+    large mixed-sign terms that cancel to residues many orders of magnitude below the partial sums (where a different
+    rounding or accumulation order in the chain shows up in every bit of the result), (c) both mixed.  Options fused_stem
+    = 0 (VALU stem kernel + conv kernel), 1 (one fused kernel), 2 (stem op alone on the matrix-pipe chain) must give the
+    same bits; BN1 is the identity and the 1x1 heads copy channels, so the chain's result reaches the outputs unscaled."""
+    import torch.nn as nn
+    from rtpe.third_party.pose_higher_hrnet import Engine, ProgramBuilder
+    L = nat.lib()
+    g = torch.Generator().manual_seed(77)
+    H, W, n = 64, 96, 3
+    conv1, bn1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+    conv2, bn2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+    heads = [nn.Conv2d(64, 34, 1, bias=True), nn.Conv2d(64, 17, 1, bias=True)]
+    tiny = 2.0 ** -24                                           # the smallest positive fp16 (denormal)
+    with torch.no_grad():
+        w1 = (torch.rand(conv1.weight.shape, generator=g) * 2 - 1)
+        w1[:16] = torch.sign(w1[:16]) * tiny * torch.randint(1, 512, w1[:16].shape, generator=g)      # (a) denormal weights
+        w1[16:32] = torch.sign(w1[16:32]) * (1.0 + torch.randint(0, 4, w1[16:32].shape, generator=g) / 1024.0)   # (b) +-(1 + k/1024)
+        conv1.weight.copy_(w1)
+        conv2.weight.zero_()
+        for c in range(64):
+            conv2.weight[c, c, 1, 1] = 1.0                      # conv2 = the centre tap of channel c: a stride-2 copy
+        for bn in (bn1, bn2):
+            bn.weight.fill_(1.0); bn.bias.zero_(); bn.running_mean.zero_(); bn.running_var.fill_(1.0 - bn.eps)
+        for hd, off in zip(heads, (0, 30)):
+            hd.weight.zero_(); hd.bias.zero_()
+            for c in range(hd.out_channels):
+                hd.weight[c, (off + c) % 64, 0, 0] = 1.0
+    for mod in [conv1, conv2] + heads:
+        mod.half()
+    b = ProgramBuilder(f32=False)
+    t = b.stem(conv1, bn1)
+    t = b.conv(t, conv2, bn2, relu=True)
+    b.conv(t, heads[0], None, out_flag=nat.F_OUT_PREDS, nhwc=False)
+    b.conv(t, heads[1], None, out_flag=nat.F_OUT_REFINED, nhwc=False)
+    eng = Engine(b.finish(), 0)
+    x = torch.randn(n, 3, H, W, generator=g)
+    x[0] = torch.sign(x[0]) * tiny * torch.randint(1, 1024, x[0].shape, generator=g)                   # (a) denormal inputs
+    x[1] = torch.sign(x[1]) * (1024.0 + torch.randint(0, 8, x[1].shape, generator=g))                  # (b) +-(1024 + k): huge cancelling terms
+    x[2, :, ::2] = torch.sign(x[2, :, ::2]) * tiny * 3.0                                                # (c) mixed
+    xin = x.to("cuda:0")
+    outs = {}
+    try:
+        with torch.no_grad():
+            for mode in (0, 1, 2):
+                nat.check(L.rtpe_set_option(b"fused_stem", mode))
+                outs[mode] = [t_.cpu() for t_ in eng.forward(xin, torch.float32)]
+    finally:
+        nat.check(L.rtpe_set_option(b"fused_stem", 1))
+    for mode in (1, 2):
+        for a_, b_ in zip(outs[0], outs[mode]):
+            assert torch.equal(a_.view(torch.int32), b_.view(torch.int32)), "fused_stem %d differs from the VALU stem" % mode
+    p = outs[0][0]
+    # the cases did reach the chain: denormal-range outputs, exact-cancellation residues and ordinary values are all present
+    assert (p[0].abs() > 0).any() and p[0].abs().max() < 1e-2 and p[1].abs().max() > 1.0
+    assert torch.isfinite(p).all()
+
+
 STREAM_CASES = [
     # cin, cout, H, W, N, residual: enough (tile, cout block) units that every persistent workgroup of the
     # streaming kernel walks several of them (halo buffer ring, weight ring, residual sets two units ahead)
