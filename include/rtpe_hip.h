@@ -65,7 +65,7 @@ extern "C" {
 #define RTPE_DTYPE_F32 2
 
 const char* rtpe_last_error_string(void);
-/* ABI revision: 4 = option "stream_pc" and ConvTile kind 3 are gone (a tuned-shape
+/* ABI revision: 4 = option "head_direct"; option "stream_pc" and ConvTile kind 3 are gone (a tuned-shape
  * file that names kind 3 is refused by rtpe_hrnet_import_tuned); the Python binding
  * refuses a library of another revision (RTPE_LIBRARY);
  * 3 = tuned-shape records have 11 integers (RTPE_TUNED_INTS);
@@ -271,7 +271,10 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * the fused kernel's conv1 code (its multiply-add chain on the matrix pipe; a test setting).  Same bits in all three.
  * "conv64" (env RTPE_CONV64): the 3x3 stride-1 convs with 64 input and 64 output channels and no residual (conv2 of layer1's
  * Bottlenecks) run 1 = on persistent workgroups with double-buffered halo tiles and register-resident weights
- * (csrc/conv64.hip; default, and one more launch shape for the autotuner), 0 = on the one-workgroup-per-tile kernel. */
+ * (csrc/conv64.hip; default, and one more launch shape for the autotuner), 0 = on the one-workgroup-per-tile kernel.
+ * "head_direct" (env RTPE_HEAD_DIRECT): the 1x1 heads with 48 input channels and fp32 NCHW output run 1 = on the direct scheme
+ * with an NCHW epilogue (csrc/conv_direct.hip conv1x1_head_kernel; default; maps whose pixel count per image is a multiple of
+ * 32), 0 = on the launch shape chosen for the layer (one workgroup per tile).  Same bits. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */

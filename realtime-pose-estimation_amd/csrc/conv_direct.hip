@@ -172,6 +172,187 @@ __global__ void __launch_bounds__(kDWaves * 64) conv1x1_direct_kernel(const Dire
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two heads (final_layers, pose_higher_hrnet.py:447-483, :674, :683: Conv2d(48 -> 34 / 17, k = 1, bias), fp32 NCHW out,
+// head 0 also NHWC into the buffer the transposed conv reads): the same direct scheme for Cin = 48 - two k-steps, the
+// second half-padded (its lanes of channels 48..63 read zeros: out-of-range offsets) - with an NCHW epilogue.  A wave takes 32 consecutive pixels (two MFMA column tiles) per step, so that a
+// channel's piece of the step is one whole 128-byte line of its fp32 plane; the finished values go channel-major through
+// the wave's slab (two pixels per 4-byte write) and come back as one 8-byte read per lane = four pixels of one channel.
+// Round 5, verdict item 3a: on the one-workgroup-per-tile kernel these layers took 152 + 85 us for 380 + 177 MB (staging,
+// k loop and epilogue of a workgroup are serial); here nothing is staged and nothing waits for a barrier.
+struct HeadArgs {
+  const _Float16* x;
+  const _Float16* w;       // packed fragments of the plan (one cout block of mt row tiles, 2 k-steps)
+  const float* alpha;
+  const float* beta;
+  _Float16* y;             // NHWC output or nullptr
+  float* y_nchw;           // fp32 (N, nchw_channels, H, W)
+  unsigned P, HW;          // pixels in all, per image (HW % 32 == 0)
+  int in_ld, out_ld, cout_store, nchw_channels, relu, round_conv;
+  unsigned x_bytes;
+};
+
+template <int MB>
+__global__ void __launch_bounds__(kDWaves * 64) conv1x1_head_kernel(const HeadArgs a) {
+  constexpr int ROWB = MB * 32 + 16;                     // pixel-major slab: bytes per pixel row (NHWC pieces)
+  constexpr int CP = 32 * 2 + 8;                         // channel-major slab: bytes per channel row of 32 pixels
+  constexpr int SLAB = 32 * ROWB > MB * 16 * CP ? 32 * ROWB : MB * 16 * CP;
+  constexpr int CH = MB * 2;
+  constexpr int NITR = (32 * CH + 63) / 64;              // NHWC row pieces per lane and step
+  __shared__ __attribute__((aligned(16))) char smem[kDWaves * SLAB + 2 * MB * 16 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  float* const bn = reinterpret_cast<float*>(smem + kDWaves * SLAB);
+  for (int i = tid; i < 2 * MB * 16; i += kDWaves * 64) bn[i] = i < MB * 16 ? a.alpha[i] : a.beta[i - MB * 16];
+  half8 wf[MB][2];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      wf[m][k] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(a.w) + ((size_t)(k * MB + m) * 64 + lane) * 16);
+  __syncthreads();
+  char* const slab = smem + wv * SLAB;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const unsigned n_steps = (a.P + 31u) / 32u;
+  const unsigned stride = gridDim.x * kDWaves;
+  unsigned t = blockIdx.x * kDWaves + wv;
+  const int in_ld2 = a.in_ld * 2;
+  const uint32_t bcol = (uint32_t)(r * in_ld2 + g * 16);
+  auto load_b = [&](unsigned step, u32x4 (&b)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const uint32_t base = (step * 32u + nt * 16u) * (uint32_t)in_ld2 + bcol;
+      // k-step 1: channels 32..63, of which 48..63 do not exist.  Those lanes ask for an out-of-range offset (zeros): the bytes
+      // behind a pixel's 48 channels are whatever lies there - the next pixel, or, in the 96-channel buffer head 0 reads, the
+      // very channels head 0 writes, or stale workspace bytes that may be NaN patterns (NaN x zero weight = NaN)
+      b[nt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)base, 0, 0));
+      b[nt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, g < 2 ? (int)(base + 64) : (int)0x80000000, 0, 0));
+    }
+  };
+  u32x4 bcur[2][2], bnxt[2][2];
+  if (t < n_steps) load_b(t, bcur);
+  for (; t < n_steps; t += stride) {
+    const unsigned tn = t + stride;
+    if (tn < n_steps) load_b(tn, bnxt);
+    float4v acc[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[m][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[m][k], __builtin_bit_cast(half8, bcur[nt][k]), acc[m][nt], 0, 0, 0);
+    // bias / BN with the wrapper's rounding points
+    half4 o[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float4v al = *reinterpret_cast<const float4v*>(bn + m * 16 + g * 4);
+      const float4v be = *reinterpret_cast<const float4v*>(bn + MB * 16 + m * 16 + g * 4);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (a.round_conv) {
+          o[m][nt] = bn_round_d(acc[m][nt], al, be);
+        } else {
+          float2v lo{acc[m][nt][0], acc[m][nt][1]}, hi{acc[m][nt][2], acc[m][nt][3]};
+          lo = __builtin_elementwise_fma(lo, float2v{al[0], al[1]}, float2v{be[0], be[1]});
+          hi = __builtin_elementwise_fma(hi, float2v{al[2], al[3]}, float2v{be[2], be[3]});
+          const half2v olo = __builtin_convertvector(lo, half2v), ohi = __builtin_convertvector(hi, half2v);
+          o[m][nt] = half4{olo[0], olo[1], ohi[0], ohi[1]};
+        }
+      }
+    }
+    if (a.y != nullptr) {
+      // NHWC: pixel-major rows of the slab, whole 16-byte pieces (as conv1x1_direct_kernel)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<half4*>(slab + (nt * 16 + r) * ROWB + m * 32 + g * 8) = o[m][nt];
+#pragma unroll
+      for (int it = 0; it < NITR; ++it) {
+        const int c = it * 64 + lane;
+        const int pw = c / CH, slot = c - pw * CH;
+        const unsigned p = t * 32u + (unsigned)pw;
+        if (c < 32 * CH && slot * 8 < a.cout_store && p < a.P) {
+          half8 v = *reinterpret_cast<const half8*>(slab + pw * ROWB + slot * 16);
+          if (a.relu) {
+            short8 bsh = __builtin_bit_cast(short8, v);
+            bsh = bsh & ~(bsh >> 15);
+            v = __builtin_bit_cast(half8, bsh);
+          }
+          store16_wt(a.y + (size_t)p * a.out_ld + slot * 8, v);
+        }
+      }
+    }
+    // NCHW fp32: channel-major slab (the wave's own: the pixel-major rows above are read, in program order, before)
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<_Float16*>(slab + (m * 16 + g * 4 + j) * CP + (nt * 16 + r) * 2) = o[m][nt][j];
+    {
+      const unsigned p0 = t * 32u;                       // the step's 32 pixels lie in one image (HW % 32 == 0)
+      const unsigned n = p0 / a.HW, pin = p0 - n * a.HW;
+      float* const yb = a.y_nchw + (size_t)n * a.nchw_channels * a.HW + pin;
+      const int n_pieces = a.nchw_channels * 8;
+      for (int i = lane; i < n_pieces; i += 64) {
+        const int c = i >> 3, q = i & 7;
+        if (p0 + (unsigned)q * 4u < a.P) {
+          const half4 h = *reinterpret_cast<const half4*>(slab + c * CP + q * 8);
+          float4v out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = (float)h[e];
+            out[e] = a.relu ? (x > 0.f ? x : 0.f) : x;
+          }
+          *reinterpret_cast<float4v*>(yb + (size_t)c * a.HW + q * 4) = out;
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) bcur[nt][k] = bnxt[nt][k];
+  }
+}
+
+// heads this kernel takes: 1x1, 48 input channels (one chunk of 48, two k-steps), at most 48 padded output channels in one
+// cout block, fp32 NCHW output, whole 32-pixel steps inside an image
+bool conv_head_supports(const ConvPlan& p, const ConvArgs& c) {
+  return p.esize == 2 && p.tapw == 1 && p.in_mul == 1 && p.dil == 1 && p.cc == 48 && p.kc == 2 && p.n_cchunks == 1 && p.n_cb == 1 &&
+         (p.mt == 2 || p.mt == 3) && c.cin == 48 && c.y_nchw != nullptr && c.nchw_f32 && c.res == nullptr && c.o_mul == 1 &&
+         c.n_cls == 0 && ((unsigned)c.H_in * (unsigned)c.W_in) % 32u == 0 && c.x_bytes > 0 && c.x_bytes < 0x80000000ull &&
+         c.in_ld % 8 == 0 && (c.y == nullptr || c.out_ld % 8 == 0) && c.nchw_channels <= p.mt * 16 &&
+         c.in_cs == p.cc && ((uintptr_t)c.y_nchw & 15) == 0;
+}
+
+template <int MB>
+static int launch_head(const HeadArgs& a, hipStream_t s) {
+  const unsigned n_steps = (a.P + 31u) / 32u;
+  unsigned gx = (n_steps + kDWaves - 1) / kDWaves;
+  if (gx > 256u * 8u) gx = 256u * 8u;                    // ~8 workgroups per CU: the waves loop
+  hipLaunchKernelGGL((conv1x1_head_kernel<MB>), dim3(gx), dim3(kDWaves * 64), 0, s, a);
+  RTPE_HIP_CHECK(hipGetLastError());
+  return RTPE_OK;
+}
+
+int conv_head_launch(const ConvPlan& p, const ConvArgs& c, hipStream_t s) {
+  RTPE_REQUIRE(conv_head_supports(p, c), "head conv: unsupported layer (cin %d cout %d)", c.cin, c.cout);
+  HeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = c.x; a.w = c.w; a.alpha = c.alpha; a.beta = c.beta; a.y = c.y; a.y_nchw = reinterpret_cast<float*>(c.y_nchw);
+  a.P = (unsigned)c.N * (unsigned)c.H_in * (unsigned)c.W_in;
+  a.HW = (unsigned)c.H_in * (unsigned)c.W_in;
+  a.in_ld = c.in_ld; a.out_ld = c.out_ld; a.cout_store = c.cout_store; a.nchw_channels = c.nchw_channels;
+  a.relu = c.relu; a.round_conv = c.round_conv; a.x_bytes = (unsigned)c.x_bytes;
+  return p.mt == 2 ? launch_head<2>(a, s) : launch_head<3>(a, s);
+}
+
 template <int KS, int MB>
 static int launch_direct(const DirectArgs& a, int n_blocks_y, hipStream_t s) {
   const unsigned n_tiles = (a.P + 15u) / 16u;

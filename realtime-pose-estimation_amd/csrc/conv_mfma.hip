@@ -473,17 +473,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if constexpr (ES == 2) {
-              // two neighbouring pixels (lanes r, r + 1 of a 16-lane row) as ONE 4-byte write by the even lane: 2-byte
-              // writes of both lanes into one dword are a bank conflict each (counter: 17 % of the LDS cycles)
-              const _Float16 own = (_Float16)acc[m][nt][j];
-              const uint32_t lo = (uint32_t)__builtin_bit_cast(unsigned short, own);
-              const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
-              if ((r & 1) == 0)
-                *reinterpret_cast<uint32_t*>(obuf + (m * 16 + g * 4 + j) * CPITCH + (nt * 16 + r) * 2) = lo | (hi << 16);
-            } else {
-              *reinterpret_cast<T*>(obuf + (m * 16 + g * 4 + j) * CPITCH + (nt * 16 + r) * ES) = (T)acc[m][nt][j];
-            }
+            // (2-byte writes: two neighbouring lanes share a dword - a bank conflict each, 17 % of this kernel's LDS cycles.
+            // Pairing them with a DPP row shift into one 4-byte write was tried: correct here, but the same code in the
+            // direct head kernel gave wrong values for three of four channels - not worth the risk for a store-bound phase)
+            *reinterpret_cast<T*>(obuf + (m * 16 + g * 4 + j) * CPITCH + (nt * 16 + r) * ES) = (T)acc[m][nt][j];
           }
     }
     constexpr int QUADS = NT * 4;

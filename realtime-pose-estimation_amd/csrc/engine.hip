@@ -78,10 +78,10 @@ struct rtpe_hrnet {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "head_direct"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_HEAD_DIRECT"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -747,6 +747,12 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         if (tile.kind == 5 && !(direct_ok && a.res == nullptr && !plane[d.in_t] && !plane[d.out_t] && get_option(kOptConv64) != 0))
           tile = conv_make_tile(o.plan[k], N, a.H_pos, a.W_pos, true, /*allow_conv64=*/false);
         conv_fill_args(o.geom[k], o.plan[k], tile, &a);
+        // the heads (1x1, 48 input channels, fp32 NCHW out): the direct scheme with an NCHW epilogue (conv_direct.hip),
+        // whatever launch shape was chosen or tuned for the layer (option "head_direct")
+        if (!merge && force == nullptr && get_option(kOptHeadDirect) != 0 && conv_head_supports(o.plan[k], a)) {
+          RTPE_HP_LAUNCH(rc = conv_head_launch(o.plan[k], a, s));
+          continue;
+        }
         if (merge) {
           // class k's weights and offsets go into the argument block of class 0; the launch follows the last class
           if (k == 0) { merged = a; merged_tile = tile; merged.n_cls = 4; }
@@ -1170,6 +1176,12 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
     if (it != h->tuned.end() && it->second[op * 4].nt) t = it->second[op * 4];
   }
   if (t.kind == 5 && (d.res_t >= 0 || (d.flags & RTPE_F_NO_NHWC))) t = conv_make_tile(o.plan[0], N, Hp, Wp, true, false);   // as run() does
+  if ((d.flags & (RTPE_F_OUT_PREDS | RTPE_F_OUT_REFINED)) && d.kind == RTPE_OP_CONV && d.ksize == 1 && d.cin == 48 && d.res_t < 0 &&
+      !(d.flags & RTPE_F_F32) && get_option(kOptHeadDirect) != 0 && o.plan[0].n_cb == 1 && (o.plan[0].mt == 2 || o.plan[0].mt == 3) &&
+      ((unsigned)Hi * (unsigned)Wi) % 32u == 0) {       // head on the direct scheme (conv_direct.hip): 32 pixels per wave step
+    out8[0] = o.plan[0].mt; out8[1] = 2; out8[2] = 4; out8[3] = 1; out8[4] = 32; out8[5] = 48; out8[6] = 1; out8[7] = -400001;
+    return RTPE_OK;
+  }
   if (o.pair && get_option(kOptPair1x1) != 0) {     // 1x1 pair (conv_pair.hip): 16-pixel tiles per wave, 8 waves
     out8[0] = o.pair == 1 ? 16 : 4; out8[1] = 1; out8[2] = 8; out8[3] = 1; out8[4] = 16; out8[5] = o.pair == 1 ? 64 : 256; out8[6] = 1;
     out8[7] = o.pair == 1 ? -800001 : -800002;

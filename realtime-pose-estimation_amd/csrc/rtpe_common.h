@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kNumOptions = 8 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kOptHeadDirect = 8, kNumOptions = 9 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -232,6 +232,9 @@ size_t conv64_lds();
 int conv64_grid(int N, int H_pos, int W_pos);
 int conv64_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
+// the two heads (1x1, 48 input channels, fp32 NCHW output, head 0 also NHWC) on the direct scheme (conv_direct.hip)
+bool conv_head_supports(const ConvPlan& p, const ConvArgs& a);
+int conv_head_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,

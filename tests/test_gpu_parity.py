@@ -261,6 +261,84 @@ def test_stem_and_nchw_head_epilogues(nat, hw, n, f32in):
         assert err.max() <= 2.0 and same > 0.97
 
 
+@pytest.mark.parametrize("hw,n", [((64, 96), 2), ((160, 224), 3), ((32, 32), 1), ((32, 32), 5), ((256, 256), 9), ((640, 640), 2)])
+def test_direct_head_kernel_is_bit_identical(nat, hw, n):
+    """csrc/conv_direct.hip conv1x1_head_kernel (option "head_direct"): the two heads (reference pose_higher_hrnet.py:447-483:
+    Conv2d(48 -> 34 / 17, k = 1, bias), fp32 NCHW out, one of them also NHWC) without a staged tile - two k-steps, the
+    second one half zero-weight padding, 32 pixels per wave step, channel-major slab for the NCHW rows.  Same packed weights
+    and k order as the one-workgroup-per-tile kernel: the same bits (option 0), and the fp16 PyTorch-CPU ops within the
+    usual two fp16 steps.  Sizes: fewer steps than waves (one 32 x 32 image: 8 steps), images of different size classes,
+    more steps than the grid holds (the waves loop).  (H and W are multiples of 32, so a head's map always has a multiple of
+    32 pixels; other maps - single-layer callers - stay on the tile kernel: conv_head_supports.)"""
+    import torch.nn as nn
+    from rtpe.third_party.pose_higher_hrnet import Engine, ProgramBuilder
+    H, W = hw
+    L = nat.lib()
+    g = torch.Generator().manual_seed(H * 13 + W)
+    conv1, bn1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64)
+    mid, bnm = nn.Conv2d(64, 48, 1, bias=False), nn.BatchNorm2d(48)
+    heads = [nn.Conv2d(48, 34, 1, bias=True), nn.Conv2d(48, 17, 1, bias=True)]
+    with torch.no_grad():
+        conv1.weight.copy_((torch.rand(conv1.weight.shape, generator=g) * 2 - 1) / 27 ** 0.5)
+        mid.weight.copy_((torch.rand(mid.weight.shape, generator=g) * 2 - 1) / 8.0)
+        for bn in (bn1, bnm):
+            bn.weight.copy_(torch.rand(bn.num_features, generator=g) * 0.4 + 0.8)
+            bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.05)
+            bn.running_var.copy_(torch.rand(bn.num_features, generator=g) * 0.2 + 0.9)
+        for hd in heads:
+            hd.weight.copy_((torch.rand(hd.weight.shape, generator=g) * 2 - 1) / 7.0)
+            hd.bias.copy_(torch.randn(hd.out_channels, generator=g) * 0.1)
+    for mod in [conv1, mid] + heads:
+        mod.half()
+    b = ProgramBuilder(f32=False)
+    t = b.stem(conv1, bn1)
+    t = b.conv(t, mid, bnm, relu=True)
+    t34 = b.conv(t, heads[0], None, out_flag=nat.F_OUT_PREDS)            # NHWC (read by the conv below) and NCHW
+    b.conv(t, heads[1], None, out_flag=nat.F_OUT_REFINED, nhwc=False)
+    eng = Engine(b.finish(), 0)
+    x = torch.randn(n, 3, H, W, generator=g).to("cuda:0")
+    outs = []
+    try:
+        with torch.no_grad():
+            for on in (1, 0):
+                nat.check(L.rtpe_set_option(b"head_direct", on))
+                assert (eng.op_tile(2, n, H, W)[7] == -400001) == (on == 1)
+                outs.append([t_.cpu() for t_ in eng.forward(x, torch.float32)])
+    finally:
+        nat.check(L.rtpe_set_option(b"head_direct", 1))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_.view(torch.int32), b_.view(torch.int32))
+    with torch.no_grad():
+        y = F.conv2d(x.cpu().half(), conv1.weight, None, 2, 1)
+        y = F.relu(bn1.float().eval()(y.float()).half())
+        y = F.relu(bnm.float().eval()(F.conv2d(y, mid.weight).float()).half())
+        want = [F.conv2d(y, hd.weight, hd.bias).float() for hd in heads]
+    for got, w_ in zip(outs[0], want):
+        gotn, wn = got.numpy(), w_.numpy()
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(wn), 0.25))) - 10)
+        assert (np.abs(gotn - wn) / ulp).max() <= 2.0 and (gotn == wn).mean() > 0.97
+
+
+def test_direct_heads_do_not_change_the_network_output(nat, teacher):
+    """the whole teacher with the heads on the direct kernel (default) and on the one-workgroup-per-tile kernel: the same
+    bits, head 0's NHWC copy (the transposed conv's input) included - it feeds everything behind it"""
+    model, sd = teacher("W2")
+    L = nat.lib()
+    for n, hw in ((2, (640, 640)), (3, (256, 384)), (1, (96, 160))):
+        x = synth.make_images(n, hw[0], hw[1], seed=31).to("cuda:0")
+        outs = []
+        for on in (1, 0):
+            nat.check(L.rtpe_set_option(b"head_direct", on))
+            try:
+                with torch.no_grad():
+                    preds, refined = model(x)
+                outs.append((preds.cpu().numpy(), refined.cpu().numpy()))
+            finally:
+                nat.check(L.rtpe_set_option(b"head_direct", 1))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), hw
+
+
 @pytest.mark.parametrize("hw,n,f32in", [((64, 96), 2, True), ((160, 224), 3, True), ((32, 32), 1, False), ((96, 352), 5, True),
                                         ((256, 256), 9, True)])
 def test_fused_stem_layer_level(nat, hw, n, f32in):
@@ -1867,7 +1945,7 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0",
-               RTPE_FUSED_STEM="0", RTPE_CONV64="0")
+               RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
@@ -1916,7 +1994,7 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
-               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
