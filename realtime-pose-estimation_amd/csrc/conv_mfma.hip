@@ -546,7 +546,12 @@ ConvPlan conv_make_plan(const ConvGeom& g) {
   // tiles of 2-4 channel chunks; 96 output channels per workgroup stage them once instead of once per 48-channel
   // block (256 -> 96: 577 -> 368 us; 96 -> 192: 85 -> 63 us; 192 -> 384: 123 -> 99 us)
   static const int wide = env_int("RTPE_CONV_MT6", 1);
-  if (wide && !dc && g.stride == 2 && g.ksize == 3 && (g.esize == 0 || g.esize == 2) && g.cout % 96 == 0 && g.cin >= 96)
+  // round 5: also with 48 input channels (48 -> 96 / 192 / 384 of the fuse layers): on the streaming kernel every 48-cout block
+  // of a tile pulls the (2 th + 1) x (2 tw + 1) halo through its own compute unit - 54 KiB for 12 KiB of output; 96 couts per
+  // workgroup on 8 x 8 tiles halve the halo bytes per output
+  static const int wide48 = env_int("RTPE_CONV_MT6_48", 1);
+  if (wide && !dc && g.stride == 2 && g.ksize == 3 && (g.esize == 0 || g.esize == 2) && g.cout % 96 == 0 &&
+      (g.cin >= 96 || (wide48 && g.cin == 48)))
     p.mt = 6;
   p.cout_pad = round_up(g.cout, 16 * p.mt);
   p.n_cb = p.cout_pad / (16 * p.mt);
@@ -682,7 +687,9 @@ static bool stream_tile(const ConvPlan& p, const TileCand& c, int N, int H_pos, 
   // stride 1: 4 or 5 pixel tiles per wave; stride 2 (4x the halo per output pixel): 2, and only with
   // resident weights (the halo buffers leave no room for the weight ring)
   if (!conv_stream_supports(p) || c.waves < 4) return false;
-  if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != 2 || p.n_cchunks != 1)) return false;
+  // (96-cout workgroups, mt = 6: their 84 KiB of resident weights leave room for the 17 x 17 halo of an 8 x 8 tile only)
+  if (p.in_mul == 1 ? (c.nt != 4 && c.nt != 5) : (c.nt != (p.mt == 6 ? 1 : 2) || p.n_cchunks != 1)) return false;
+  if (p.mt == 6 && p.in_mul != 2) return false;
   const int hh = (c.th - 1) * p.in_mul + 3, hw = (c.tw - 1) * p.in_mul + 3;
   if (hw * 6 > 256) return false;                        // a halo row is at most 4 DMA instructions
   const size_t in_tile = (size_t)hh * conv_row_pitch(p, c.tw, 2);

@@ -569,7 +569,8 @@ size_t conv_stream_lds(const ConvPlan& p, int buf_bytes, int n_bufs, int n_wslot
 
 bool conv_stream_supports(const ConvPlan& p) {
   return p.esize == 2 && p.dil == 1 && p.cc == kCC && p.pstride == kPStride && p.tapw == 3 && p.kc == kKC &&
-         (p.in_mul == 1 || p.in_mul == 2) && p.mt <= 3 && (p.n_cchunks & (p.n_cchunks - 1)) == 0;
+         (p.in_mul == 1 || p.in_mul == 2) && (p.mt <= 3 || (p.mt == 6 && p.in_mul == 2 && p.n_cchunks == 1)) &&
+         (p.n_cchunks & (p.n_cchunks - 1)) == 0;
 }
 
 int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
@@ -590,7 +591,7 @@ int conv_stream_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, 
                (size_t)t.waves * t.nt * 16 * (p.mt * 32 + 16) <= (size_t)t.buf_bytes, "streaming conv: tile buffer too small");
 #define RTPE_S(MTv, NTv, Wv) \
   if (p.mt == MTv && t.nt == NTv && t.waves == Wv) return launch_stream<MTv, NTv, Wv>(t, a, s);
-  RTPE_S(3, 4, 4) RTPE_S(3, 5, 4) RTPE_S(3, 5, 5) RTPE_S(3, 2, 4)
+  RTPE_S(3, 4, 4) RTPE_S(3, 5, 4) RTPE_S(3, 5, 5) RTPE_S(3, 2, 4) RTPE_S(6, 1, 4)
   RTPE_S(2, 4, 4) RTPE_S(2, 5, 4) RTPE_S(2, 5, 5)
   RTPE_S(1, 4, 4) RTPE_S(1, 5, 4) RTPE_S(1, 5, 5)
 #undef RTPE_S
