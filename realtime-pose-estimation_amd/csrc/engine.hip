@@ -78,10 +78,10 @@ struct rtpe_hrnet {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "head_direct"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_HEAD_DIRECT"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "head_direct", "deconv48"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_HEAD_DIRECT", "RTPE_DECONV48"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -759,7 +759,13 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
           merged.w_c[k] = a.w;
           merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
           merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
-          if (k == o.n_geom - 1) RTPE_HP_LAUNCH(rc = conv_launch(o.plan[0], merged_tile, merged, s));
+          if (k == o.n_geom - 1) {
+            // the four classes on one persistent kernel that shares their halo tiles (deconv48.hip, option "deconv48")
+            if (force == nullptr && get_option(kOptDeconv48) != 0 && deconv48_supports(o.plan[0], merged))
+              RTPE_HP_LAUNCH(rc = deconv48_launch(o.plan[0], merged, s));
+            else
+              RTPE_HP_LAUNCH(rc = conv_launch(o.plan[0], merged_tile, merged, s));
+          }
           continue;
         }
         if (pairs_on && o.pair == 1 && direct_ok) {       // launched together with the next op (conv_pair.hip)
@@ -1114,7 +1120,9 @@ extern "C" int rtpe_deconv4x4s2_nhwc(const void* x, int32_t N, int32_t H, int32_
       merged.w_c[k] = a.w;
       merged.lo_yc[k] = a.lo_y; merged.lo_xc[k] = a.lo_x;
       merged.oy_c[k] = a.oy_add; merged.ox_c[k] = a.ox_add;
-      if (k == 3) rc = conv_launch(plans[0], merged_tile, merged, s);
+      if (k == 3)
+        rc = get_option(kOptDeconv48) != 0 && deconv48_supports(plans[0], merged) ? deconv48_launch(plans[0], merged, s)
+                                                                                   : conv_launch(plans[0], merged_tile, merged, s);
       continue;
     }
     rc = conv_launch(p, tile, a, s);
@@ -1180,6 +1188,12 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
       !(d.flags & RTPE_F_F32) && get_option(kOptHeadDirect) != 0 && o.plan[0].n_cb == 1 && (o.plan[0].mt == 2 || o.plan[0].mt == 3) &&
       ((unsigned)Hi * (unsigned)Wi) % 32u == 0) {       // head on the direct scheme (conv_direct.hip): 32 pixels per wave step
     out8[0] = o.plan[0].mt; out8[1] = 2; out8[2] = 4; out8[3] = 1; out8[4] = 32; out8[5] = 48; out8[6] = 1; out8[7] = -400001;
+    return RTPE_OK;
+  }
+  if (dc && get_option(kOptDeconv48) != 0 && t.kind == 0 && d.res_t < 0 && !(d.flags & RTPE_F_NO_NHWC) && !h->plane_ok[d.in_t] &&
+      !h->plane_ok[d.out_t] && o.plan[0].mt == 3 && o.plan[0].n_cb == 1 && o.plan[0].cout_pad == 48 && o.plan[0].n_cchunks <= 2) {
+    // the four classes on one persistent kernel (deconv48.hip): 8 x 16 input positions per tile, wave k = class k
+    out8[0] = 3; out8[1] = 2; out8[2] = 4; out8[3] = 8; out8[4] = 16; out8[5] = 48; out8[6] = 1; out8[7] = -300001;
     return RTPE_OK;
   }
   if (o.pair && get_option(kOptPair1x1) != 0) {     // 1x1 pair (conv_pair.hip): 16-pixel tiles per wave, 8 waves

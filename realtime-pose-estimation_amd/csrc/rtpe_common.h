@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kOptHeadDirect = 8, kNumOptions = 9 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kOptHeadDirect = 8, kOptDeconv48 = 9, kNumOptions = 10 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -235,6 +235,9 @@ int conv_direct_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // the two heads (1x1, 48 input channels, fp32 NCHW output, head 0 also NHWC) on the direct scheme (conv_direct.hip)
 bool conv_head_supports(const ConvPlan& p, const ConvArgs& a);
 int conv_head_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
+// deconv48.hip: the four sub-pixel classes of the k4 s2 transposed conv to 48 channels on one persistent kernel
+bool deconv48_supports(const ConvPlan& p, const ConvArgs& merged);
+int deconv48_launch(const ConvPlan& p, const ConvArgs& merged, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,

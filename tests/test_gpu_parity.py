@@ -1804,6 +1804,64 @@ def test_deconv_layer(nat, case):
     assert err.max() <= 2.0 and (got == want).mean() > 0.97, (err.max(), (got == want).mean())
 
 
+@pytest.mark.parametrize("case", [(96, 48, 20, 28, 2), (48, 48, 16, 16, 2), (96, 48, 8, 16, 1), (96, 48, 5, 7, 3), (48, 48, 37, 50, 1),
+                                  (96, 48, 160, 160, 3), (96, 40, 24, 33, 2)],
+                         ids=lambda c: "deconv_%d-%d_%dx%d_n%d" % c)
+@pytest.mark.parametrize("plain", [False, True], ids=["bn_relu", "plain"])
+def test_deconv48_kernel_is_bit_identical(nat, case, plain):
+    """csrc/deconv48.hip (option "deconv48"): the four sub-pixel classes of ConvTranspose2d(k4 s2 p1) + BN + ReLU
+    (pose_higher_hrnet.py:513-524) on one persistent kernel - wave k = class k, weights in registers, one shared halo tile,
+    whole output rows from a transpose buffer.  Same packed weights and k order as the one-workgroup-per-tile kernel: the same
+    bits (option 0).  Sizes: exactly one tile, maps smaller than a tile, ragged edges in both directions, more tiles than the
+    grid holds (the workgroups loop), fewer than 48 output channels (40: masked 16-byte pieces); with the layer's flags (the
+    conv output's own fp16 rounding before BN, ReLU) and without them."""
+    cin, cout, H, W, N = case
+    flags = 0 if plain else nat.F_RELU | nat.F_ROUND_CONV
+    L = nat.lib()
+    g = torch.Generator().manual_seed(cin + cout + H * 3 + W)
+    x = torch.randn(N, H, W, cin, generator=g).half()
+    w = ((torch.rand(cin, cout, 4, 4, generator=g) * 2 - 1) / (cin * 4) ** 0.5).half()
+    alpha = (torch.rand(cout, generator=g) * 0.4 + 0.8).numpy()
+    beta = (torch.randn(cout, generator=g) * 0.1).numpy()
+    dev = torch.device("cuda:0")
+    xd = x.to(dev)
+    fpt = ctypes.POINTER(ctypes.c_float)
+    wn = w.contiguous().numpy()
+    outs = []
+    try:
+        for on in (1, 0):
+            nat.check(L.rtpe_set_option(b"deconv48", on))
+            # (the canary value is a NaN pattern no kernel writes: every output element must be overwritten)
+            yd = torch.full((N, 2 * H, 2 * W, cout), float("nan"), dtype=torch.float16, device=dev)
+            nat.check(L.rtpe_deconv4x4s2_nhwc(xd.data_ptr(), N, H, W, cin, wn.ctypes.data, alpha.ctypes.data_as(fpt),
+                                              beta.ctypes.data_as(fpt), cout, flags, yd.data_ptr(),
+                                              nat.stream_ptr(dev)))
+            outs.append(yd.cpu())
+    finally:
+        nat.check(L.rtpe_set_option(b"deconv48", 1))
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (outs[0] != outs[1]).sum().item()
+
+
+def test_deconv48_does_not_change_the_network_output(nat, teacher):
+    """the whole teacher with the transposed conv on the persistent kernel (default) and on the one-workgroup-per-tile
+    kernel: the same bits (the layer feeds the final stage's BasicBlocks and the second head)"""
+    model, sd = teacher("W2")
+    L = nat.lib()
+    for n, hw in ((2, (640, 640)), (3, (256, 384)), (1, (96, 160))):
+        x = synth.make_images(n, hw[0], hw[1], seed=37).to("cuda:0")
+        outs = []
+        for on in (1, 0):
+            nat.check(L.rtpe_set_option(b"deconv48", on))
+            try:
+                with torch.no_grad():
+                    preds, refined = model(x)
+                outs.append((preds.cpu().numpy(), refined.cpu().numpy()))
+            finally:
+                nat.check(L.rtpe_set_option(b"deconv48", 1))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), hw
+
+
 def test_fuse_layer(nat):
     """the fuse sum with nearest-upsampled lower-resolution terms: bit-exact (fp16 adds in the module's order)"""
     g = torch.Generator().manual_seed(11)
@@ -1945,7 +2003,7 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0",
-               RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0")
+               RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
@@ -1994,7 +2052,7 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
-               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
