@@ -274,7 +274,11 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * (csrc/conv64.hip; default, and one more launch shape for the autotuner), 0 = on the one-workgroup-per-tile kernel.
  * "head_direct" (env RTPE_HEAD_DIRECT): the 1x1 heads with 48 input channels and fp32 NCHW output run 1 = on the direct scheme
  * with an NCHW epilogue (csrc/conv_direct.hip conv1x1_head_kernel; default; maps whose pixel count per image is a multiple of
- * 32), 0 = on the launch shape chosen for the layer (one workgroup per tile).  Same bits. */
+ * 32), 0 = on the launch shape chosen for the layer (one workgroup per tile).  Same bits.
+ * "deconv48" (env RTPE_DECONV48; added within ABI revision 4: an older library answers RTPE_E_INVALID): transposed convs
+ * (k4 s2 p1) from 48 or 96 input channels to at most 48 output channels run 1 = with all four sub-pixel classes on one
+ * persistent kernel that shares their halo tiles (csrc/deconv48.hip; default), 0 = as four classes in one grid of the
+ * one-workgroup-per-tile kernel.  Same bits. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */
