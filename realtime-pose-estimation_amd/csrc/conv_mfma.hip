@@ -121,8 +121,17 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   // m_split > 1: a packed cout block (MT * m_split cout tiles) is shared out to m_split workgroups of MT tiles each
   // (small grids - batch 1, the /16 and /32 branches: three times the workgroups, a third of the k chain each; the
   // k order of an output does not change)
+  // wsplit == 2: the shares of a packed cout block are dealt to the two HALVES of a workgroup's waves instead of to two
+  // workgroups (ConvTile::mrun < 0): both halves read the same staged tile, each wave twice the pixels - the weight fragments a
+  // wave pulls through L1 per MFMA halve (stride-2 convs with >= 96 input channels: four waves of MT = 6, NT = 2 each fetched the
+  // same 6 KiB per k step, 128 B per clock and CU against the vector cache's 64)
+  const uint32_t wsplit = a.wsplit > 1 ? 2u : 1u;
+  const int pwv = WAVES / (int)wsplit;                         // waves that share the tile's pixels
+  const int wgx = wsplit > 1 ? wv / pwv : 0;                   // this wave's half
+  const int wvp = wv - wgx * pwv;                              // its index among the waves of that half
   const uint32_t m_split = a.m_split > 1 ? (uint32_t)a.m_split : 1u;
-  const uint32_t n_cbs = (uint32_t)a.n_cb * m_split;
+  const uint32_t wg_split = m_split / wsplit;                 // shares dealt to workgroups
+  const uint32_t n_cbs = (uint32_t)a.n_cb * wg_split;
   const uint32_t per_tile = n_cbs * (uint32_t)(a.n_cls > 0 ? a.n_cls : 1);
   const uint32_t tq = slot / per_tile;
   // an XCD owns a CONTIGUOUS eighth of the row-major tile list: neighbouring tiles share their halo rows / columns and
@@ -141,8 +150,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   const uint32_t tyi = fdiv(t, a.div_tiles_x);
   const uint32_t txi = t - tyi * a.tiles_x;
   const uint32_t cbs = sub - (uint32_t)cls * n_cbs;
-  const int cb = (int)(cbs / m_split);                        // packed cout block
-  const int msel = (int)(cbs - (uint32_t)cb * m_split);       // this workgroup's share of it
+  const int cb = (int)(cbs / wg_split);                       // packed cout block
+  const int msel = (int)(cbs - (uint32_t)cb * wg_split) * (int)wsplit + wgx;   // this workgroup's (this half's) share of it
   const int mt_pack = MT * (int)m_split;
   const int co_base = (cb * mt_pack + msel * MT) * 16;        // first output channel of this workgroup
   const int py0 = tyi * a.th, px0 = txi * a.tw;
@@ -167,7 +176,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
   int pixbase[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const uint32_t p = (wv * NT + nt) * 16 + r;
+    const uint32_t p = (wvp * NT + nt) * 16 + r;
     const uint32_t oy = fdiv(p, a.div_tw);
     const uint32_t ox = p - oy * a.tw;
     pixbase[nt] = (int)(oy * a.in_mul * a.rowb + ox * (a.deint ? 1 : a.in_mul) * a.pstride);
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     for (int it = 0; it < (kEarlyRes ? NITG : 0); ++it) {
       const int c = it * 64 + lane;
       const int pw = c / CHG, slot = c - pw * CHG;
-      const uint32_t p = wv * NT * 16 + pw;
+      const uint32_t p = wvp * NT * 16 + pw;
       const uint32_t oyt = fdiv(p, a.div_tw);
       const uint32_t oxt = p - oyt * a.tw;
       const int py = py0 + (int)oyt, px = px0 + (int)oxt;
@@ -393,7 +402,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) orow[j] = o[j];
       if (a.y_nchw != nullptr && !nchw_rows) {          // heads: NCHW fp32/fp16 straight from the registers
-        const uint32_t p = (wv * NT + nt) * 16 + r;
+        const uint32_t p = (wvp * NT + nt) * 16 + r;
         const uint32_t oyt = fdiv(p, a.div_tw);
         const uint32_t oxt = p - oyt * a.tw;
         const int py = py0 + (int)oyt, px = px0 + (int)oxt;
@@ -425,7 +434,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
       const int c = it * 64 + lane;                 // chunk index inside this wave's pixels
       if (c >= NT * 16 * CH) continue;
       const int pw = c / CH, slot = c - pw * CH;    // pixel of the wave, 16-byte slot of its row
-      const uint32_t p = wv * NT * 16 + pw;
+      const uint32_t p = wvp * NT * 16 + pw;
       const uint32_t oyt = fdiv(p, a.div_tw);
       const uint32_t oxt = p - oyt * a.tw;
       const int py = py0 + (int)oyt, px = px0 + (int)oxt;
@@ -484,7 +493,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     n_ch = n_ch > MT * 16 ? MT * 16 : n_ch;
     for (int idx = lane; idx < QUADS * n_ch; idx += 64) {
       const int c = idx / QUADS, q = idx - c * QUADS;
-      const uint32_t p = wv * NT * 16 + q * 4;
+      const uint32_t p = wvp * NT * 16 + q * 4;
       const uint32_t oyt = fdiv(p, a.div_tw);
       const uint32_t oxt = p - oyt * a.tw;
       const int py = py0 + (int)oyt, px = px0 + (int)oxt;
@@ -677,7 +686,7 @@ static const TileCand kCands[] = {
 static size_t tile_lds(const ConvPlan& p, int th, int tw, int waves, int nt, int mrun = 0) {
   const int hh = (th - 1) * p.in_mul + (p.tapw - 1) * p.dil + 1;
   const size_t in_tile = (size_t)hh * conv_row_pitch(p, tw, 0);
-  const size_t out_tile = (size_t)waves * nt * 16 * ((mrun ? mrun : p.mt) * 16 * p.esize + 16);   // epilogue transpose buffer
+  const size_t out_tile = (size_t)waves * nt * 16 * ((mrun ? (mrun > 0 ? mrun : -mrun) : p.mt) * 16 * p.esize + 16);   // epilogue transpose buffer
   return (size_t)kTapTableBytes + (in_tile > out_tile ? in_tile : out_tile);
 }
 
@@ -805,6 +814,17 @@ ConvTile conv_make_tile(const ConvPlan& p, int N, int H_pos, int W_pos, bool all
       best.nt = c.nt; best.waves = c.waves; best.th = c.th; best.tw = c.tw; best.lds_bytes = lds;
     }
   }
+  // RTPE_CONV_WAVE_HALVES=2: untuned launches of the stride-2 3x3 convs put the two halves of their cout block on the two halves
+  // of the workgroup's waves (mrun < 0; the autotuner times that shape by itself: conv_enum_tiles; the switch lets a test run it
+  // everywhere)
+  static const int force_halves = env_int("RTPE_CONV_WAVE_HALVES", 1);
+  if (force_halves == 2 && p.esize == 2 && p.in_mul == 2 && p.tapw == 3 && p.mt % 2 == 0 && conv_has_variant(p.mt / 2, 4, 4)) {
+    ConvTile h;
+    memset(&h, 0, sizeof(h));
+    h.nt = 4; h.waves = 4; h.th = 8; h.tw = 16; h.mrun = -(p.mt / 2);
+    h.lds_bytes = tile_lds(p, h.th, h.tw, 4, 4, h.mrun);
+    if (h.lds_bytes <= 160 * 1024) return h;
+  }
   // RTPE_CONV_MRUN=m: untuned launches share every cout block out to mt / m workgroups where that shape exists (the
   // autotuner times these shapes for small grids by itself: conv_enum_tiles; the switch lets a test run them everywhere)
   static const int force_mrun = env_int("RTPE_CONV_MRUN", 0);
@@ -844,7 +864,8 @@ void conv_fill_args(const ConvGeom& g, const ConvPlan& p, const ConvTile& t, Con
   a->div_tiles_x = make_fastdiv(a->tiles_x);
   a->div_tiles_xy = make_fastdiv(a->tiles_x * a->tiles_y);
   a->n_cb = p.n_cb;
-  a->m_split = (t.kind == 0 && t.mrun > 0) ? p.mt / t.mrun : 1;
+  a->m_split = (t.kind == 0 && t.mrun != 0) ? p.mt / (t.mrun > 0 ? t.mrun : -t.mrun) : 1;
+  a->wsplit = (t.kind == 0 && t.mrun < 0) ? 2 : 0;
   if (a->in_cs == 0) a->in_cs = p.cc;
   if (a->out_cs == 0) a->out_cs = p.mt * 16;
   if (a->res_cs == 0) a->res_cs = p.mt * 16;
@@ -867,7 +888,7 @@ static int launch_variant(const ConvTile& t, const ConvArgs& a, int n_cb, hipStr
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   const unsigned n_tiles = (unsigned)(a.N * a.tiles_x * a.tiles_y);
-  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb * (unsigned)(a.m_split > 1 ? a.m_split : 1) *
+  dim3 grid(((n_tiles + 7u) / 8u) * 8u * (unsigned)n_cb * (unsigned)((a.m_split > 1 ? a.m_split : 1) / (a.wsplit > 1 ? 2 : 1)) *
             (unsigned)(a.n_cls > 0 ? a.n_cls : 1));   // (tile / 8, class, cout block x share, tile % 8 = XCD)
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), t.lds_bytes, s, a);
   RTPE_HIP_CHECK(hipGetLastError());
@@ -895,6 +916,23 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
     if (w < min_waste) min_waste = w;
   }
   for (const TileCand& c : kCands) {
+    // the block's two halves on the two halves of the workgroup's waves (mrun < 0): same tile, twice the pixels per wave, half
+    // the weight fragments per wave - the stride-2 convs with two and more channel chunks, whose weights come from L2 in every
+    // k step
+    static const int wave_halves = env_int("RTPE_CONV_WAVE_HALVES", 1);
+    if (wave_halves && p.esize == 2 && p.in_mul == 2 && p.tapw == 3 && p.mt % 2 == 0 && c.waves == 4 && c.nt >= 4 && c.nt % 2 == 0 &&
+        conv_has_variant(p.mt / 2, c.nt, 4)) {
+      // candidate c describes (waves, nt, th, tw) with th * tw = 16 nt waves: the same waves and nt on HALF the pixels
+      ConvTile h;
+      memset(&h, 0, sizeof(h));
+      h.nt = c.nt; h.waves = 4; h.mrun = -(p.mt / 2);
+      h.th = c.th >= c.tw ? c.th / 2 : c.th; h.tw = c.th >= c.tw ? c.tw : c.tw / 2;
+      h.lds_bytes = tile_lds(p, h.th, h.tw, 4, c.nt, h.mrun);
+      const double hw = (double)((H_pos + h.th - 1) / h.th * h.th) * ((W_pos + h.tw - 1) / h.tw * h.tw) / ((double)H_pos * W_pos);
+      bool dup = false;
+      for (const ConvTile& o : *out) dup = dup || (o.kind == 0 && o.mrun == h.mrun && o.nt == h.nt && o.th == h.th && o.tw == h.tw);
+      if (!dup && h.lds_bytes <= 160 * 1024 && hw <= 1.35 * min_waste) out->push_back(h);
+    }
     if (p.mt == 4 && c.nt == 8) continue;
     if (p.mt == 6 && c.nt > 2 && c.waves >= 4) continue;
     if (!tiny_ok(c)) continue;
@@ -934,7 +972,7 @@ void conv_enum_tiles(const ConvPlan& p, int N, int H_pos, int W_pos, std::vector
 }
 
 int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStream_t s) {
-  RTPE_REQUIRE(t.th * t.tw == 16 * t.nt * t.waves,
+  RTPE_REQUIRE(t.th * t.tw * (t.kind == 0 && t.mrun < 0 ? 2 : 1) == 16 * t.nt * t.waves,
                "conv tile %dx%d != 16*%d*%d", t.th, t.tw, t.nt, t.waves);
   RTPE_REQUIRE(t.lds_bytes <= 160 * 1024, "conv tile needs %zu B of LDS", t.lds_bytes);
   // a launch shape belongs to one plan (halo = taps x dilation, pixel stride): never run a foreign one
@@ -954,7 +992,8 @@ int conv_launch(const ConvPlan& p, const ConvTile& t, const ConvArgs& a, hipStre
   if (t.kind == 5) return conv64_launch(p, t, a, s);
   RTPE_REQUIRE(a.in_cs == p.cc && a.out_cs == p.mt * 16 && a.res_cs == p.mt * 16,
                "conv: the one-workgroup-per-tile kernel reads and writes NHWC only");
-  const int mrun = t.mrun > 0 ? t.mrun : p.mt;
+  const int mrun = t.mrun > 0 ? t.mrun : t.mrun < 0 ? -t.mrun : p.mt;
+  RTPE_REQUIRE(t.mrun >= 0 ? a.wsplit <= 1 : (a.wsplit == 2 && t.waves % 2 == 0 && (p.mt / mrun) % 2 == 0), "conv: wave halves");
   RTPE_REQUIRE(p.mt % mrun == 0 && a.m_split == p.mt / mrun, "conv: %d cout tiles per workgroup do not divide the block of %d",
                mrun, p.mt);
 #define RTPE_V(MTv, NTv, Wv)                                                                  \

@@ -163,6 +163,8 @@ struct ConvArgs {
                          // first, then the odd ones (n_even = number of even columns): consecutive OUTPUT pixels of a tap are
                          // then consecutive LDS pixels, as with stride 1, and the B-operand reads are bank-conflict free
   int n_even;
+  int wsplit;            // one-workgroup-per-tile kernel: 2 = the shares of a packed cout block go to the two halves of a workgroup's
+                         // waves (ConvTile::mrun < 0) instead of to two workgroups; 0 / 1 = every wave multiplies all of the workgroup's tiles
   int m_split;           // one-workgroup-per-tile kernel: workgroups that share one packed cout block (ConvTile::mrun cout
                          // tiles each); 0 / 1 = one workgroup computes the whole block
   int ablate;            // profiling ablations (RTPE_STREAM_ABL): 1 skip MFMA k-loops, 2 skip residual loads + output stores, 4 skip halo DMA
@@ -192,6 +194,8 @@ struct ConvTile {       // launch-shape half of the plan (depends on N, H, W)
   int n_wslots;         // streaming: weight half-stage slots
   int mrun;             // kind 0: cout tiles (x16) per workgroup, a divisor of ConvPlan::mt (0 = all mt of them): the
                         // packed cout block is shared out to mt / mrun workgroups (small grids)
+                        // < 0: -mrun cout tiles per HALF of the workgroup's waves (two halves on one staged tile of
+                        // th * tw = 16 * nt * waves / 2 pixels): the block is shared out to mt / (2 * -mrun) workgroups
 };
 
 struct ConvGeom {       // logical layer, independent of the batch

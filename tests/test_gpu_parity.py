@@ -2059,6 +2059,53 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
         assert np.array_equal(ref[name], t.cpu().numpy()), name
 
 
+def test_cout_halves_on_wave_halves_give_the_same_bits(nat, teacher, tmp_path):
+    """stride-2 3x3 convs on the one-workgroup-per-tile kernel with the two halves of a packed cout block on the two halves of
+    the workgroup's waves (ConvTile::mrun < 0, csrc/conv_mfma.hip: same staged tile, twice the pixels per wave, half the weight
+    fragments per wave; a shape the autotuner times for these layers).  A second process runs EVERY such conv that way
+    (RTPE_CONV_WAVE_HALVES=2, untuned launches, no streaming / fused / direct kernels: the stem's conv2, the 256 -> 96
+    transition, every downsampling conv of the fuse layers) on two input sizes with ragged tiles - and must give the bits
+    this process computes with its tuned product configuration"""
+    import subprocess
+    import sys
+    model, sd = teacher("W1")
+    xs = [synth.make_images(1, 160, 224, seed=93).to("cuda:0"), synth.make_images(2, 96, 352, seed=94).to("cuda:0")]
+    want = []
+    with torch.no_grad():
+        for x in xs:
+            p, r = model(x)
+            want.append((p.cpu().numpy(), r.cpu().numpy()))
+    out = str(tmp_path / "halves.npz")
+    code = (
+        "import json, sys, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from oracle import synth\n"
+        "from rtpe.helpers import build_hrnet_w48_teacher\n"
+        "shapes = {k: tuple(v) for k, v in json.load(open(%r))['shapes'].items()}\n"
+        "sd = synth.make_state_dict(shapes, 0, 'W1')\n"
+        "m = build_hrnet_w48_teacher({'1.' + k: v for k, v in sd.items()}).to('cuda:0')\n"
+        "res = {}\n"
+        "n_halves = 0\n"
+        "for i, (n, h, w, seed) in enumerate(((1, 160, 224, 93), (2, 96, 352, 94))):\n"
+        "    x = synth.make_images(n, h, w, seed=seed)\n"
+        "    with torch.no_grad():\n"
+        "        p, r = m(x.to('cuda:0'))\n"
+        "    res['p%%d' %% i], res['r%%d' %% i] = p.cpu().numpy(), r.cpu().numpy()\n"
+        "    eng = next(iter(m[1]._engines.values()))\n"
+        "    tiles = [eng.op_tile(j, n, h, w) for j in range(len(eng.program.ops))]\n"
+        "    n_halves += sum(1 for t in tiles if t[0] < 0 and t[1] == 4 and t[2] == 4 and t[3] * t[4] == 128)\n"
+        "assert n_halves >= 40, n_halves\n"
+        "np.savez(%r, **res)\n"
+    ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"), os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
+    env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0",
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_AUTOTUNE="0",
+               RTPE_CONV_WAVE_HALVES="2")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
+    ref = np.load(out)
+    for i, (p, r) in enumerate(want):
+        assert np.array_equal(ref["p%d" % i], p) and np.array_equal(ref["r%d" % i], r), i
+
+
 def test_fused_stem_does_not_change_the_network_output(nat, teacher):
     """conv1 + bn1 + relu and conv2 + bn2 + relu of the stem (reference pose_higher_hrnet.py:363-368 / :638-643) run as ONE
     kernel that keeps the half-resolution 64-channel map in LDS (option "fused_stem", csrc/stem_fused.hip): the program
