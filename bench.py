@@ -503,7 +503,7 @@ def main():
         t = eng.op_tile(i, B, S, S)
         ds = eng.program.tensors[eng.program.ops[i].out_t].ds_log2 if eng.program.ops[i].out_t >= 0 else 1
         names[i] = "%s @/%d" % (names[i], 1 << ds) + (
-            " [m%s n%d w%d %dx%d cc%d cb%d%s]" % ((("%dx2" % -t[0]) if t[0] < 0 else str(t[0]),) + tuple(t[1:7]) + ((" FUSED-BLOCK" if t[7] == -900001 else " (in fused block)" if t[7] == -900002 else " PAIR-HEAD" if t[7] == -800001 else " PAIR" if t[7] == -800002 else " FUSED-STEM" if t[7] in (-600001, -600002) else " HEAD-DIRECT" if t[7] == -400001 else " DECONV48" if t[7] == -300001 else " CONV64" if -600000 < t[7] <= -500000 else " S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else "",)) if t[0] else "")
+            " [m%s n%d w%d %dx%d cc%d cb%d%s]" % ((("%dx2" % -t[0]) if t[0] < 0 else str(t[0]),) + tuple(t[1:7]) + ((" FUSED-BLOCK" if t[7] == -900001 else " (in fused block)" if t[7] == -900002 else " PAIR-HEAD" if t[7] == -800001 else " PAIR" if t[7] == -800002 else " FUSED-STEM" if t[7] in (-600001, -600002) else " HEAD-DIRECT" if t[7] == -400001 else " DECONV48" if t[7] == -300001 else " CONV48S2" if t[7] == -200001 else " CONV48S2 (one launch with the next %d)" % (-t[7] - 200001) if t[7] in (-200002, -200003) else " (in the CONV48S2 launch above)" if t[7] == -200009 else " CONV64" if -600000 < t[7] <= -500000 else " S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else "",)) if t[0] else "")
     for i, nm in enumerate(names):
         d = by_name.setdefault(nm, dict(n=0, ms=0.0, flops=0.0, bytes=0.0, res={}))
         d["n"] += 1

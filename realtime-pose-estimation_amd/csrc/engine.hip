@@ -39,6 +39,8 @@ struct OpState {
   int fuse;             // 1: head of a fused BasicBlock (this conv + the next run as one kernel), 2: its second conv
   int pair;             // 1: head of a 1x1 pair (conv_pair.hip: launched with the next op), 2: its tail
   int stem2;            // 1: the stem op whose conv1 runs together with the next op's conv2 (stem_fused.hip), 2: that conv op
+  int s2g;              // n > 1: first of n neighbouring 3x3 stride-2 convs from the SAME 48-channel input that run as one launch
+                        // (conv48s2.hip: the input is read once), -1: one of the others
 };
 
 }  // namespace rtpe
@@ -78,10 +80,10 @@ struct rtpe_hrnet {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace rtpe {
-static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
-static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "head_direct", "deconv48"};
-static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_HEAD_DIRECT", "RTPE_DECONV48"};
-static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static int g_options[kNumOptions] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};       // -1: not set, take the environment's value
+static const char* const kOptionNames[kNumOptions] = {"block_ring", "block_pc", "direct_1x1", "lanes", "tile_dma", "pair_1x1", "fused_stem", "conv64", "head_direct", "deconv48", "conv48s2"};
+static const char* const kOptionEnv[kNumOptions] = {"RTPE_BLOCK_RING", "RTPE_BLOCK_PC", "RTPE_DIRECT_1X1", "RTPE_LANES", "RTPE_TILE_DMA", "RTPE_PAIR_1X1", "RTPE_FUSED_STEM", "RTPE_CONV64", "RTPE_HEAD_DIRECT", "RTPE_DECONV48", "RTPE_CONV48S2"};
+static const int kOptionDefault[kNumOptions] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 int get_option(int key) {
   int v = __atomic_load_n(&g_options[key], __ATOMIC_RELAXED);
   if (v < 0) {
@@ -266,6 +268,37 @@ extern "C" int rtpe_hrnet_create(const rtpe_op_desc* ops, int32_t n_ops,
       continue;
     a1.pair = 1;
     h->ops[i + 1].pair = 2;
+  }
+  // neighbouring downsampling convs that read the same 48-channel tensor (the first convs of a fuse layer's chains from branch 0,
+  // pose_higher_hrnet.py:213-230: 48 -> 96 to branch 1, 48 -> 48 towards branches 2 and 3): one launch of conv48s2.hip reads the
+  // input once for all of them.  Static conditions here, the launch's own (sizes, layouts, option) in run()
+  for (OpState& o : h->ops) o.s2g = 0;
+  {
+    auto s2_static = [&](const OpState& o) {
+      const rtpe_op_desc& d = o.d;
+      return d.kind == RTPE_OP_CONV && d.ksize == 3 && d.stride == 2 && d.cin == 48 && (d.cout == 48 || d.cout == 96) && d.res_t < 0 &&
+             !(d.flags & (RTPE_F_NO_NHWC | RTPE_F_F32 | RTPE_F_OUT_PREDS | RTPE_F_OUT_REFINED)) && o.n_geom == 1 && o.plan[0].esize == 2 &&
+             o.plan[0].cout_pad == d.cout && d.reserved[2] <= 0;
+    };
+    static const int s2_groups = env_int("RTPE_S2_GROUPS", 1);
+    for (size_t i = 0; s2_groups && i < h->ops.size(); ++i) {
+      if (h->ops[i].s2g != 0 || !s2_static(h->ops[i])) continue;
+      const rtpe_op_desc& d0 = h->ops[i].d;
+      int n = 1, groups = d0.cout / 48;
+      while (i + n < h->ops.size() && n < 3) {
+        const OpState& on = h->ops[i + n];
+        const rtpe_op_desc& dn = on.d;
+        bool ok = s2_static(on) && dn.in_t == d0.in_t && dn.in_coff == d0.in_coff && dn.lane == d0.lane && dn.region == d0.region &&
+                  (dn.flags & RTPE_F_ROUND_CONV) == (d0.flags & RTPE_F_ROUND_CONV) && groups + dn.cout / 48 <= 4;
+        for (int m = 0; m < n && ok; ++m) ok = h->ops[i + m].d.out_t != dn.out_t && dn.out_t != d0.in_t;
+        if (!ok) break;
+        groups += dn.cout / 48;
+        ++n;
+      }
+      if (n < 2) continue;
+      h->ops[i].s2g = n;
+      for (int m = 1; m < n; ++m) h->ops[i + m].s2g = -1;
+    }
   }
   h->arena_bytes = off;
   {
@@ -561,6 +594,35 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
   memset(&pair_args, 0, sizeof(pair_args));
   bool pair_pending = false;                              // the head of a 1x1 pair waits for its tail's launch
   bool stem_pending = false;                              // the fused stem kernel ran at the stem op: the next op (conv2) is done
+  int s2_skip = 0;                                        // ops behind the first of a stride-2 group that its launch has done
+  // argument block of op j as a plain NHWC conv (conv48s2.hip's layers: no residual, no NCHW output)
+  auto s2_layer_args = [&](size_t j, ConvArgs* a) {
+    const OpState& oj = h->ops[j];
+    const rtpe_op_desc& dj = oj.d;
+    const rtpe_tensor_desc& tj = h->tensors[dj.in_t];
+    const int Hj = H >> tj.ds_log2, Wj = W >> tj.ds_log2;
+    memset(a, 0, sizeof(*a));
+    a->x = tptr(dj.in_t, dj.in_coff);
+    a->in_ld = tj.channels;
+    a->x_bytes = ((size_t)N * Hj * Wj * tj.channels - (size_t)dj.in_coff) * esz(dj.in_t);
+    a->w = reinterpret_cast<const _Float16*>(h->arena + oj.w_dev_off[0]);
+    a->alpha = reinterpret_cast<const float*>(h->arena + oj.ab_dev_off);
+    a->beta = a->alpha + oj.plan[0].cout_pad;
+    a->y = tptr(dj.out_t, dj.out_coff);
+    a->out_ld = h->tensors[dj.out_t].channels;
+    const int room = h->tensors[dj.out_t].channels - dj.out_coff;
+    a->cout_store = oj.plan[0].cout_pad < room ? oj.plan[0].cout_pad : room;
+    a->N = N; a->H_in = Hj; a->W_in = Wj;
+    a->H_full = a->H_pos = Hj / dj.stride; a->W_full = a->W_pos = Wj / dj.stride;
+    a->o_mul = 1;
+    a->relu = (dj.flags & RTPE_F_RELU) ? 1 : 0;
+    a->round_conv = (dj.flags & RTPE_F_ROUND_CONV) ? 1 : 0;
+    a->cin = dj.cin; a->cout = dj.cout;
+    a->lo_y = oj.plan[0].lo_y; a->lo_x = oj.plan[0].lo_x;
+    a->in_cs = oj.plan[0].cc; a->out_cs = oj.plan[0].mt * 16; a->res_cs = oj.plan[0].mt * 16;
+  };
+  ConvArgs s2_args[3];
+  const ConvPlan* s2_plans[3];
   int cur_region = 0;
   bool lane_used[4] = {false, false, false, false};
   auto join_lanes = [&]() -> hipError_t {
@@ -594,6 +656,8 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         for (int j : h->wait_ops[i]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
         if ((o.fuse == 1 || o.stem2 == 1) && i + 1 < h->ops.size())   // the block's second conv (the stem's conv2) is launched with this one
           for (int j : h->wait_ops[i + 1]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
+        for (int m = 1; m < o.s2g; ++m)                               // the other convs of a stride-2 group are launched with this one
+          for (int j : h->wait_ops[i + m]) RTPE_HIP_CHECK(hipStreamWaitEvent(s, h->op_event[j], 0));
       }
     }
     const bool stem_fused_on = force == nullptr && only_op < 0 && get_option(kOptFusedStem) == 1 && stem_fused_supports(H, W);
@@ -658,6 +722,21 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
                                reinterpret_cast<const _Float16*>(h->arena + o2.w_dev_off[0]),
                                reinterpret_cast<const float*>(h->arena + o2.ab_dev_off), N, Hi, Wi, s));
       }
+    } else if (d.kind == RTPE_OP_CONV && o.s2g < 0 && s2_skip > 0) {
+      --s2_skip;                // done by the launch at the group's first op
+    } else if (d.kind == RTPE_OP_CONV && o.s2g > 1 && force == nullptr && only_op < 0 && get_option(kOptConv48s2) != 0 && [&]() {
+                 for (int m = 0; m < o.s2g; ++m) {
+                   const OpState& om = h->ops[i + m];
+                   if (plane[om.d.in_t] || plane[om.d.out_t]) return false;
+                   s2_layer_args(i + m, &s2_args[m]);
+                   s2_plans[m] = &om.plan[0];
+                   if (!conv48s2_supports(om.plan[0], s2_args[m])) return false;
+                 }
+                 return true;
+               }()) {
+      // the first downsampling convs of a fuse layer's chains from one branch: one launch, the input read once
+      RTPE_HP_LAUNCH(rc = conv48s2_launch_group(s2_plans, s2_args, o.s2g, s));
+      s2_skip = o.s2g - 1;
     } else if (d.kind == RTPE_OP_CONV || d.kind == RTPE_OP_DECONV) {
       const rtpe_tensor_desc& ti = h->tensors[d.in_t];
       const int Hi = H >> ti.ds_log2, Wi = W >> ti.ds_log2;
@@ -751,6 +830,13 @@ static int run(rtpe_hrnet* h, const void* x, int x_dtype, int N, int H, int W, v
         // whatever launch shape was chosen or tuned for the layer (option "head_direct")
         if (!merge && force == nullptr && get_option(kOptHeadDirect) != 0 && conv_head_supports(o.plan[k], a)) {
           RTPE_HP_LAUNCH(rc = conv_head_launch(o.plan[k], a, s));
+          continue;
+        }
+        // the downsampling convs of the fuse layers from 48 input channels: persistent workgroups with register-resident weights
+        // (conv48s2.hip, option "conv48s2"), whatever launch shape was chosen or tuned for the layer
+        if (!merge && force == nullptr && get_option(kOptConv48s2) != 0 && !plane[d.in_t] && !(a.y != nullptr && plane[d.out_t]) &&
+            conv48s2_supports(o.plan[k], a)) {
+          RTPE_HP_LAUNCH(rc = conv48s2_launch(o.plan[k], a, s));
           continue;
         }
         if (merge) {
@@ -1003,7 +1089,7 @@ extern "C" int rtpe_conv2d_nhwc_ex(const void* x, int32_t N, int32_t H, int32_t 
   hipMemset(dbg, 0, 128);
   a.dbg = dbg;
 #endif
-  int rc = conv_launch(p, tile, a, s);
+  int rc = get_option(kOptConv48s2) != 0 && conv48s2_supports(p, a) ? conv48s2_launch(p, a, s) : conv_launch(p, tile, a, s);
   hipError_t es2 = hipStreamSynchronize(s);
 #ifdef RTPE_CONV_STAMPS
   unsigned long long hd[16];
@@ -1194,6 +1280,16 @@ extern "C" int rtpe_hrnet_op_tile(const rtpe_hrnet* h, int32_t op, int32_t N, in
       !h->plane_ok[d.out_t] && o.plan[0].mt == 3 && o.plan[0].n_cb == 1 && o.plan[0].cout_pad == 48 && o.plan[0].n_cchunks <= 2) {
     // the four classes on one persistent kernel (deconv48.hip): 8 x 16 input positions per tile, wave k = class k
     out8[0] = 3; out8[1] = 2; out8[2] = 4; out8[3] = 8; out8[4] = 16; out8[5] = 48; out8[6] = 1; out8[7] = -300001;
+    return RTPE_OK;
+  }
+  if (!dc && get_option(kOptConv48s2) != 0 && d.ksize == 3 && d.stride == 2 && d.cin == 48 && d.res_t < 0 && !(d.flags & (RTPE_F_NO_NHWC | RTPE_F_F32)) &&
+      !h->plane_ok[d.in_t] && !h->plane_ok[d.out_t] && (d.cout == 48 || d.cout == 96 || d.cout == 192 || d.cout == 384) &&
+      o.plan[0].cout_pad == d.cout && Hi % 2 == 0 && Wi % 2 == 0) {
+    // persistent stride-2 kernel (conv48s2.hip): 8 x 8 output tiles, a wave = one group of 48 output channels
+    const int gw = d.cout == 48 ? 1 : d.cout == 96 ? 2 : 4;
+    out8[0] = 3; out8[1] = 2; out8[2] = 4; out8[3] = 8; out8[4] = 8; out8[5] = 48; out8[6] = d.cout / (48 * gw);
+    // -200001: a launch of its own; -20000n (n = 2, 3): first of n convs from one input in ONE launch; -200009: one of the others
+    out8[7] = o.s2g > 1 ? -(200000 + o.s2g) : o.s2g < 0 ? -200009 : -200001;
     return RTPE_OK;
   }
   if (o.pair && get_option(kOptPair1x1) != 0) {     // 1x1 pair (conv_pair.hip): 16-pixel tiles per wave, 8 waves

@@ -45,7 +45,7 @@ inline int env_int(const char* name, int dflt) {
 #endif
 
 // run-time tuning options (rtpe_set_option): every setting gives bit-identical results
-enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kOptHeadDirect = 8, kOptDeconv48 = 9, kNumOptions = 10 };
+enum { kOptBlockRing = 0, kOptBlockPC = 1, kOptDirect1x1 = 2, kOptLanes = 3, kOptTileDma = 4, kOptPair1x1 = 5, kOptFusedStem = 6, kOptConv64 = 7, kOptHeadDirect = 8, kOptDeconv48 = 9, kOptConv48s2 = 10, kNumOptions = 11 };
 int get_option(int key);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: true the first time a kernel's
@@ -242,6 +242,11 @@ int conv_head_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // deconv48.hip: the four sub-pixel classes of the k4 s2 transposed conv to 48 channels on one persistent kernel
 bool deconv48_supports(const ConvPlan& p, const ConvArgs& merged);
 int deconv48_launch(const ConvPlan& p, const ConvArgs& merged, hipStream_t s);
+// conv48s2.hip: 3x3 stride-2 convs from 48 input channels on persistent workgroups with register-resident weights
+bool conv48s2_supports(const ConvPlan& p, const ConvArgs& a);
+int conv48s2_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
+// several such layers that read the same input view (48 / 96 output channels each, 2 or 4 groups of 48 together) as one launch
+int conv48s2_launch_group(const ConvPlan* const* plans, const ConvArgs* layers, int n, hipStream_t s);
 // fused BasicBlock of the 48-channel branches (conv_block.hip): y = relu(bn2(conv(relu(bn1(conv(x))))) + x)
 bool conv_block_supports(int cin, int cout, int H, int W);
 int conv_block_launch(const _Float16* x, int in_ld, size_t x_bytes, _Float16* y, int out_ld, const _Float16* w1,

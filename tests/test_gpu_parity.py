@@ -1862,6 +1862,72 @@ def test_deconv48_does_not_change_the_network_output(nat, teacher):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), hw
 
 
+@pytest.mark.parametrize("case", [(48, 32, 32, 2), (96, 32, 32, 2), (192, 16, 16, 3), (384, 16, 16, 2), (48, 16, 32, 1), (96, 18, 50, 3),
+                                  (192, 22, 14, 2), (384, 6, 10, 5), (48, 160, 160, 4), (96, 160, 160, 3), (192, 80, 80, 5), (384, 40, 40, 9),
+                                  (48, 2, 2, 1)],
+                         ids=lambda c: "48-%d_%dx%d_n%d" % c)
+@pytest.mark.parametrize("plain", [False, True], ids=["bn_relu", "plain"])
+def test_conv48s2_kernel_is_bit_identical(nat, case, plain):
+    """csrc/conv48s2.hip (option "conv48s2"): the 3x3 stride-2 convs from 48 input channels (downsampling convs of the fuse
+    layers, pose_higher_hrnet.py:213-230) on persistent workgroups - a wave owns one group of 48 output channels with its
+    weights in registers, halo tiles with the even columns first, whole output rows from a transpose buffer.  Same packed
+    weights and k order as the other kernels: the same bits as with the option off.  Sizes: exactly one tile, ragged tiles in
+    both directions, maps smaller than a tile, more units than the grid holds (the workgroups loop; two cout blocks for 384),
+    every output width of the network; with the layer's flags and without."""
+    cout, H, W, N = case
+    L = nat.lib()
+    g = torch.Generator().manual_seed(cout + H * 3 + W)
+    x = torch.randn(N, H, W, 48, generator=g).half()
+    w = ((torch.rand(cout, 48, 3, 3, generator=g) * 2 - 1) / (48 * 9) ** 0.5).half()
+    alpha = (torch.rand(cout, generator=g) * 0.4 + 0.8).numpy()
+    beta = (torch.randn(cout, generator=g) * 0.1).numpy()
+    flags = 0 if plain else nat.F_RELU | nat.F_ROUND_CONV
+    dev = torch.device("cuda:0")
+    xd = x.to(dev)
+    fpt = ctypes.POINTER(ctypes.c_float)
+    wn = w.contiguous().numpy()
+    outs = []
+    try:
+        for on in (1, 0):
+            nat.check(L.rtpe_set_option(b"conv48s2", on))
+            yd = torch.full((N, H // 2, W // 2, cout), float("nan"), dtype=torch.float16, device=dev)   # every element must be written
+            nat.check(L.rtpe_conv2d_nhwc(xd.data_ptr(), N, H, W, 48, wn.ctypes.data, alpha.ctypes.data_as(fpt),
+                                         beta.ctypes.data_as(fpt), cout, 3, 2, flags, None, yd.data_ptr(), nat.stream_ptr(dev)))
+            outs.append(yd.cpu())
+    finally:
+        nat.check(L.rtpe_set_option(b"conv48s2", 1))
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (outs[0] != outs[1]).sum().item()
+
+
+def test_conv48s2_does_not_change_the_network_output(nat, teacher):
+    """the whole teacher with the 48-input downsampling convs on the persistent kernel (default; the sibling convs of a fuse layer
+    that read branch 0's map as ONE launch) and on the launch shapes chosen for them otherwise: the same bits; the program has
+    25 such layers"""
+    model, sd = teacher("W2")
+    L = nat.lib()
+    for n, hw in ((2, (640, 640)), (3, (256, 384)), (1, (96, 160))):
+        x = synth.make_images(n, hw[0], hw[1], seed=41).to("cuda:0")
+        outs = []
+        for on in (1, 0):
+            nat.check(L.rtpe_set_option(b"conv48s2", on))
+            try:
+                with torch.no_grad():
+                    preds, refined = model(x)
+                outs.append((preds.cpu().numpy(), refined.cpu().numpy()))
+                if on:
+                    eng = next(iter(model[1]._engines.values()))
+                    marks = [eng.op_tile(i, n, hw[0], hw[1])[7] for i in range(len(eng.program.ops))]
+                    # 25 layers; the first convs of the chains from branch 0 of a fuse layer run as one launch: 4 pairs (stage 3)
+                    # and 2 triples (stage 4)
+                    assert sum(1 for m in marks if -200010 < m <= -200001) == 25
+                    assert marks.count(-200002) == 4 and marks.count(-200003) == 2 and marks.count(-200009) == 8
+            finally:
+                nat.check(L.rtpe_set_option(b"conv48s2", 1))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), hw
+
+
 def test_fuse_layer(nat):
     """the fuse sum with nearest-upsampled lower-resolution terms: bit-exact (fp16 adds in the module's order)"""
     g = torch.Generator().manual_seed(11)
@@ -2003,7 +2069,7 @@ def test_streaming_fused_plane_major_network_equals_the_plain_kernel_network(nat
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0", RTPE_PAIR_1X1="0",
-               RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0")
+               RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_CONV48S2="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     assert np.array_equal(ref["p"], preds.cpu().numpy()) and np.array_equal(ref["r"], refined.cpu().numpy())
@@ -2052,7 +2118,7 @@ def test_shared_out_cout_blocks_give_the_same_bits(nat, teacher, tmp_path, mrun,
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"),
          os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), mrun, at_least, out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0",
-               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_CONV48S2="0", RTPE_AUTOTUNE="0", RTPE_CONV_MRUN=str(mrun))
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)
     for name, t in (("p16", p16), ("r16", r16), ("p32", p32), ("r32", r32)):
@@ -2098,7 +2164,7 @@ def test_cout_halves_on_wave_halves_give_the_same_bits(nat, teacher, tmp_path):
         "np.savez(%r, **res)\n"
     ) % (ROOT, os.path.join(ROOT, "realtime-pose-estimation_amd"), os.path.join(ROOT, "tests", "golden", "w48_shapes.json"), out)
     env = dict(os.environ, RTPE_FUSE_BLOCKS="0", RTPE_PLANE_MAJOR="0", RTPE_CONV_STREAM="0", RTPE_DIRECT_1X1="0", RTPE_LANES="0",
-               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_AUTOTUNE="0",
+               RTPE_PAIR_1X1="0", RTPE_FUSED_STEM="0", RTPE_CONV64="0", RTPE_HEAD_DIRECT="0", RTPE_DECONV48="0", RTPE_CONV48S2="0", RTPE_AUTOTUNE="0",
                RTPE_CONV_WAVE_HALVES="2")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
     ref = np.load(out)

@@ -55,7 +55,7 @@ def main():
         tag = ""
         if t[0]:
             kind = (" PAIR-HEAD (launched with the next op)" if t[7] == -800001 else " PAIR (both 1x1 convs)" if t[7] == -800002 else
-                    " FUSED-STEM" if t[7] in (-600001, -600002) else " HEAD-DIRECT" if t[7] == -400001 else " DECONV48" if t[7] == -300001 else " CONV64 %d workgroups" % (-t[7] - 500000) if -600000 < t[7] <= -500000 else
+                    " FUSED-STEM" if t[7] in (-600001, -600002) else " HEAD-DIRECT" if t[7] == -400001 else " DECONV48" if t[7] == -300001 else " CONV48S2" if t[7] == -200001 else " CONV48S2 (one launch with the next %d)" % (-t[7] - 200001) if t[7] in (-200002, -200003) else " (in the CONV48S2 launch above)" if t[7] == -200009 else " CONV64 %d workgroups" % (-t[7] - 500000) if -600000 < t[7] <= -500000 else
                     " S%d/%d" % (-t[7] % 100000, -t[7] // 100000) if t[7] <= -100000 else " P%d" % -t[7]) if t[7] < 0 else ""
             tag = " [m%s n%d w%d %dx%d cc%d cb%d%s]" % ((("%dx2" % -t[0]) if t[0] < 0 else str(t[0]),) + tuple(t[1:7]) + (kind,))
         key = "%s @/%d%s" % (nm, 1 << ds, tag)
