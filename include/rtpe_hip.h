@@ -278,7 +278,11 @@ int rtpe_hrnet_autotune_aux(rtpe_hrnet* h, const void* x, int32_t x_dtype, const
  * "deconv48" (env RTPE_DECONV48; added within ABI revision 4: an older library answers RTPE_E_INVALID): transposed convs
  * (k4 s2 p1) from 48 or 96 input channels to at most 48 output channels run 1 = with all four sub-pixel classes on one
  * persistent kernel that shares their halo tiles (csrc/deconv48.hip; default), 0 = as four classes in one grid of the
- * one-workgroup-per-tile kernel.  Same bits. */
+ * one-workgroup-per-tile kernel.  Same bits.
+ * "conv48s2" (env RTPE_CONV48S2; added within ABI revision 4): 3x3 stride-2 convs from 48 input channels to 48 / 96 / 192 / 384
+ * output channels run 1 = on persistent workgroups with register-resident weights, neighbouring ones that read the same input
+ * (the first downsampling convs of a fuse layer) as ONE launch (csrc/conv48s2.hip; default), 0 = each on the launch shape chosen
+ * for it.  Same bits. */
 int rtpe_set_option(const char* name, int32_t value);
 /* The value an option has NOW (set by rtpe_set_option, else the environment's, else the default): what the next
  * launch will use.  bench.py names the kernel it reports from this, not from the environment. */
