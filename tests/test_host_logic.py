@@ -73,6 +73,30 @@ def test_program_compiles_to_fused_ops(built):
                 assert prog.tensors[op.res_t].slot != prog.tensors[op.out_t].slot
 
 
+def test_sibling_downsampling_convs_are_neighbours_in_the_program(built):
+    """the first convs of a fuse layer's downsampling chains from branch 0 (reference pose_higher_hrnet.py:213-230: 48 -> 96
+    towards branch 1, 48 -> 48 towards branches 2 and 3) read the same map; HighResolutionModule.emit puts them next to each other
+    on one lane, so that the executor can run them as one launch (csrc/conv48s2.hip, OpState::s2g): 4 pairs in stage 3, 2 triples
+    in stage 4, nothing else changes (same op counts as the reference's module list)"""
+    from rtpe.helpers import build_hrnet_w48_teacher
+    prog = build_hrnet_w48_teacher()[1].compile_program()
+    ops = list(prog.ops)
+    is_s2 = lambda op: op.kind == built.OP_CONV and op.ksize == 3 and op.stride == 2 and op.cin == 48 and op.cout in (48, 96)
+    runs, i = [], 0
+    while i < len(ops):
+        if is_s2(ops[i]):
+            j = i + 1
+            while j < len(ops) and is_s2(ops[j]) and (ops[j].in_t, ops[j].in_coff, ops[j].lane, ops[j].region) == \
+                    (ops[i].in_t, ops[i].in_coff, ops[i].lane, ops[i].region):
+                j += 1
+            runs.append([ops[k].cout for k in range(i, j)])
+            i = j
+        else:
+            i += 1
+    groups = [r for r in runs if len(r) > 1]
+    assert sorted(groups) == [[96, 48]] * 4 + [[96, 48, 48]] * 2, runs
+
+
 def test_no_cpu_fallback(built):
     from rtpe.helpers import build_hrnet_w48_teacher
     from rtpe.third_party.pose_higher_hrnet import PoseHigherResolutionNet
@@ -419,11 +443,12 @@ def test_rounding_points_survive_the_compiler(built, tmp_path):
     64-channel kernel spills registers to scratch memory"""
     import re
     for name in ("conv_mfma.hip", "conv_stream.hip", "conv_block.hip", "conv_direct.hip", "conv_pair.hip",
-                 "stem_fused.hip", "conv64.hip"):
+                 "stem_fused.hip", "conv64.hip", "deconv48.hip", "conv48s2.hip"):
         dis = _device_code(built, tmp_path, name)
         fused = re.findall(r"v_fma_mix(?:lo|hi)_f16", dis)
         assert not fused, "%s: %d fused fma + fp16 conversions" % (name, len(fused))
-        if name in ("stem_fused.hip", "conv64.hip"):
+        if name in ("stem_fused.hip", "conv64.hip", "deconv48.hip", "conv48s2.hip"):
+            # (the round-5 kernels keep 36 / 42 weight fragments per wave in registers: 220-236 of the 256 a wave may have)
             assert "scratch_" not in dis, name + ": registers spilled to scratch memory"
     dis = _device_code(built, tmp_path, "stem_fused.hip")
     assert dis.count("v_mfma_f32_16x16x4_f32") >= 4 * 7 and dis.count("v_mfma_f32_16x16x32_f16") >= 72
