@@ -51,9 +51,57 @@ __global__ void __launch_bounds__(256) fuse_kernel(const FuseArgs a) {
   }
 }
 
+// The same sum with one workgroup row per output row (blockIdx.y = n * H + y) and a thread per 16-byte piece of it: 32-bit
+// indices and one division by a constant per thread, where the grid-stride form above spends three 64-bit divisions per piece
+// (the sums of the 160 x 160 maps ran at 0.43-0.57 of the HBM rate: they were bound by that arithmetic).  Same adds in the same
+// order: same bits.
+template <typename T>
+__global__ void __launch_bounds__(256) fuse_rows_kernel(const FuseArgs a, const FastDiv div_c8, const FastDiv div_h) {
+  constexpr int EPS = 16 / (int)sizeof(T);
+  const int c8 = a.C / EPS;
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= (uint32_t)(a.W * c8)) return;
+  const uint32_t x = fdiv(p, div_c8), cs = p - x * (uint32_t)c8;
+  const uint32_t n = fdiv(blockIdx.y, div_h), y = blockIdx.y - n * (uint32_t)a.H;
+  uint4 raw[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {                            // all loads first
+    if (t >= a.n_terms) break;
+    const int u = a.term_up[t];
+    const uint32_t hs = (uint32_t)a.H >> u, ws = (uint32_t)a.W >> u;
+    raw[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.term[t]) +
+                                             ((size_t)(n * hs + (y >> u)) * ws + (x >> u)) * a.term_ld[t] + cs * EPS);
+  }
+  float acc[EPS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= a.n_terms) break;
+    T v[EPS];
+    __builtin_memcpy(v, &raw[t], 16);
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) acc[j] = t == 0 ? (float)v[j] : (float)(T)(acc[j] + (float)v[j]);
+  }
+  T o[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) o[j] = (T)((acc[j] > 0.f || !a.relu) ? acc[j] : 0.f);
+  uint4 oraw;
+  __builtin_memcpy(&oraw, o, 16);
+  store16_wt(reinterpret_cast<T*>(a.y) + ((size_t)(n * (uint32_t)a.H + y) * a.W + x) * a.out_ld + cs * EPS, oraw);
+}
+
 int fuse_launch(const FuseArgs& a, hipStream_t s) {
   const int eps = a.f32 ? 4 : 8;
   RTPE_REQUIRE(a.C % eps == 0 && a.n_terms >= 1 && a.n_terms <= 4, "fuse: C=%d terms=%d", a.C, a.n_terms);
+  static const int rows = env_int("RTPE_FUSE_ROWS", 1);
+  const long row_pieces = (long)a.W * (a.C / eps), n_rows = (long)a.N * a.H;
+  if (rows && n_rows <= 65535 && n_rows < (1l << 20) && row_pieces < (1l << 20) && (long)a.N * a.H * a.W < (1l << 31)) {
+    const dim3 grid((unsigned)((row_pieces + 255) / 256), (unsigned)n_rows);
+    const FastDiv dc = make_fastdiv((uint32_t)(a.C / eps)), dh = make_fastdiv((uint32_t)a.H);
+    if (a.f32) hipLaunchKernelGGL(fuse_rows_kernel<float>, grid, dim3(256), 0, s, a, dc, dh);
+    else hipLaunchKernelGGL(fuse_rows_kernel<_Float16>, grid, dim3(256), 0, s, a, dc, dh);
+    RTPE_HIP_CHECK(hipGetLastError());
+    return RTPE_OK;
+  }
   const size_t total = (size_t)a.N * a.H * a.W * (a.C / eps);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
